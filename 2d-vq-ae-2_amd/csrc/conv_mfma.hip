@@ -1,0 +1,318 @@
+// fp32 implicit-GEMM convolution on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Replaces the torch.nn.Conv2d call sites of PreActFixupResBlock.forward
+// (reference vq_ae/layers/conv_block.py:196-216): 1x1 "proj2d", 3x3 circular "same2d",
+// 2x2/stride-2 "down2d", with the Fixup scalar-bias / ELU pre-op fused into the operand load and the
+// scale / bias / residual / next-conv-pre-activation fused into the epilogue.
+//
+// GEMM view: M = B*Ho*Wo output pixels (NHWC, so the GEMM row index IS the output pixel index),
+// N = Cout, K = taps*Cin with k = tap*Cin + ci.  One 256-thread workgroup (4 waves, one per SIMD,
+// two workgroups resident per CU) owns a 128 x NT output tile; every K-step stages a 128 x KC
+// activation tile (gathered per tap: circular wrap / stride / zero pad resolved per pixel) and an
+// NT x KC weight tile through LDS (register prefetch of step s+1 under the MFMAs of step s, two LDS
+// buffers, one barrier per step).  fp32 MFMA issues one 32x32x2 every 64 cycles per SIMD, so operand
+// staging is almost free; the kernel is bound by the matrix pipe (157 TFLOP/s dense fp32 peak).
+//
+// LDS tiles are [row][KC + 4] floats: the +4 (one 16-B slot, odd slot stride) makes the
+// ds_read_b128 fragment reads conflict-free (MI355X_MICROARCH.md §LDS).  Lane (i = l&31, h = l>>5)
+// reads 4 consecutive k at 8u + 4h and feeds them to 4 consecutive MFMAs; A and B use the same k
+// permutation, which the sum over k does not see.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvK {
+    const float* __restrict__ x;
+    const float* __restrict__ w;         // packed [Npad][Ktot]
+    const float* __restrict__ bias_vec;  // [Cout] or null
+    const float* residual;               // [M][Cout] or null; may alias y (in-place residual add)
+    float* y;                            // [M][Cout]
+    int B, H, W, Cin, Cout, Ho, Wo, ks, stride, pad, pad_mode;
+    int M, Ktot, n_chunks, n_steps;
+    int pre_mode;
+    float pre_a, pre_b;
+    int has_scale, has_bias_s, has_act;
+    float scale, bias_s, act_a, act_b;
+};
+
+__device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : expm1f(v); }
+
+template <int NT, int KC>
+__global__ __launch_bounds__(256, 2)
+void conv_mfma_kernel(const ConvK p) {
+    constexpr int LDR = KC + 4;                      // LDS row stride (floats)
+    constexpr int WN = (NT == 128) ? 2 : 1;          // waves along N
+    constexpr int WM = 4 / WN;                       // waves along M
+    constexpr int MI = 128 / (WM * 32);              // 32-row MFMA tiles per wave along M
+    constexpr int NI = NT / (WN * 32);               // along N
+    constexpr int A_PT = KC / 8;                     // float4 per thread for the A tile
+    constexpr int B_F4 = NT * KC / 4;                // float4 in the B tile
+    constexpr int B_PT = (B_F4 + 255) / 256;
+    constexpr int C4 = KC / 4;                       // float4 per tile row
+
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 * (128 + NT) * LDR floats
+    float* const Abuf0 = lds;
+    float* const Bbuf0 = lds + 2 * 128 * LDR;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs; give each XCD a
+    // contiguous range of M tiles so 3x3 halo rows are shared in one L2 (speed only).
+    int tile_m;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        tile_m = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int m0 = tile_m * 128;
+    const int n0 = blockIdx.y * NT;
+
+    // per-thread A-gather bookkeeping: A_PT pixels, one float4 column each
+    const int a_c4 = tid % C4;
+    int a_row[A_PT], a_oy[A_PT], a_ox[A_PT];
+    int64_t a_img[A_PT];
+    bool a_ok[A_PT];
+#pragma unroll
+    for (int i = 0; i < A_PT; ++i) {
+        const int row = tid / C4 + i * (256 / C4);
+        a_row[i] = row;
+        const int m = m0 + row;
+        a_ok[i] = m < p.M;
+        const int mm = a_ok[i] ? m : 0;
+        const int hw = p.Ho * p.Wo;
+        const int b = mm / hw, rem = mm - b * hw;
+        a_oy[i] = rem / p.Wo;
+        a_ox[i] = rem - a_oy[i] * p.Wo;
+        a_img[i] = (int64_t)b * p.H * p.W;
+    }
+
+    float4 ra[A_PT], rb[B_PT];
+    bool ra_valid[A_PT];
+
+    auto load_global = [&](int s) {
+        const int tap = s / p.n_chunks, chunk = s - tap * p.n_chunks;
+        const int dy = tap / p.ks, dx = tap - dy * p.ks;
+#pragma unroll
+        for (int i = 0; i < A_PT; ++i) {
+            int iy = a_oy[i] * p.stride + dy - p.pad;
+            int ix = a_ox[i] * p.stride + dx - p.pad;
+            bool ok = a_ok[i];
+            if (p.pad_mode == VQAE_PAD_CIRCULAR) {
+                iy = iy < 0 ? iy + p.H : (iy >= p.H ? iy - p.H : iy);
+                ix = ix < 0 ? ix + p.W : (ix >= p.W ? ix - p.W : ix);
+            } else {
+                ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            }
+            ra_valid[i] = ok;
+            if (ok) {
+                const float* src = p.x + ((a_img[i] + (int64_t)iy * p.W + ix) * p.Cin + chunk * KC + a_c4 * 4);
+                ra[i] = *reinterpret_cast<const float4*>(src);
+            } else {
+                ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_PT; ++i) {
+            const int f = tid + i * 256;
+            if (B_F4 % 256 == 0 || f < B_F4) {
+                const int n = f / C4, c4 = f % C4;
+                rb[i] = *reinterpret_cast<const float4*>(p.w + (int64_t)(n0 + n) * p.Ktot + (int64_t)s * KC + c4 * 4);
+            }
+        }
+    };
+
+    auto store_lds = [&](int buf) {
+        float* As = Abuf0 + buf * 128 * LDR;
+        float* Bs = Bbuf0 + buf * NT * LDR;
+#pragma unroll
+        for (int i = 0; i < A_PT; ++i) {
+            float4 v = ra[i];
+            if (p.pre_mode != VQAE_PRE_NONE && ra_valid[i]) {
+                v.x += p.pre_a; v.y += p.pre_a; v.z += p.pre_a; v.w += p.pre_a;
+                if (p.pre_mode == VQAE_PRE_BIAS_ELU_BIAS) {
+                    v.x = elu1(v.x) + p.pre_b; v.y = elu1(v.y) + p.pre_b;
+                    v.z = elu1(v.z) + p.pre_b; v.w = elu1(v.w) + p.pre_b;
+                }
+            }
+            *reinterpret_cast<float4*>(As + a_row[i] * LDR + a_c4 * 4) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_PT; ++i) {
+            const int f = tid + i * 256;
+            if (B_F4 % 256 == 0 || f < B_F4) {
+                const int n = f / C4, c4 = f % C4;
+                *reinterpret_cast<float4*>(Bs + n * LDR + c4 * 4) = rb[i];
+            }
+        }
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    const int frag_row = lane & 31;
+    const int frag_k = 4 * (lane >> 5);
+
+    load_global(0);
+    store_lds(0);
+    __syncthreads();
+
+    for (int s = 0; s < p.n_steps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < p.n_steps) load_global(s + 1);
+
+        const float* As = Abuf0 + buf * 128 * LDR + (wm * MI * 32 + frag_row) * LDR + frag_k;
+        const float* Bs = Bbuf0 + buf * NT * LDR + (wn * NI * 32 + frag_row) * LDR + frag_k;
+#pragma unroll
+        for (int u = 0; u < KC / 8; ++u) {
+            float a[MI][4], b[NI][4];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const float4 v = *reinterpret_cast<const float4*>(As + mi * 32 * LDR + 8 * u);
+                a[mi][0] = v.x; a[mi][1] = v.y; a[mi][2] = v.z; a[mi][3] = v.w;
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const float4 v = *reinterpret_cast<const float4*>(Bs + ni * 32 * LDR + 8 * u);
+                b[ni][0] = v.x; b[ni][1] = v.y; b[ni][2] = v.z; b[ni][3] = v.w;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][r], b[ni][r], acc[mi][ni], 0, 0, 0);
+        }
+
+        if (s + 1 < p.n_steps) store_lds(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const int col = lane & 31;
+    const int rhalf = 4 * (lane >> 5);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int n = n0 + wn * NI * 32 + ni * 32 + col;
+        const bool n_ok = n < p.Cout;
+        const float bv = (p.bias_vec && n_ok) ? p.bias_vec[n] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * MI * 32 + mi * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
+                if (n_ok && m < p.M) {
+                    float t = acc[mi][ni][r];
+                    if (p.has_scale) { t = t * p.scale; t = t + p.bias_s; }
+                    else if (p.has_bias_s) { t = t + p.bias_s; }
+                    if (p.bias_vec) t = t + bv;
+                    const int64_t o = (int64_t)m * p.Cout + n;
+                    if (p.residual) t = t + p.residual[o];
+                    if (p.has_act) t = elu1(t + p.act_a) + p.act_b;
+                    p.y[o] = t;
+                }
+            }
+        }
+    }
+}
+
+__global__ void pack_weight_kernel(const float* __restrict__ w, int cout, int cin, int ks, int npad,
+                                   float* __restrict__ out) {
+    const int ktot = ks * ks * cin;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)npad * ktot) return;
+    const int n = (int)(i / ktot), k = (int)(i % ktot);
+    const int tap = k / cin, ci = k % cin;
+    out[i] = (n < cout) ? w[((int64_t)n * cin + ci) * ks * ks + tap] : 0.f;
+}
+
+template <int NT, int KC>
+int launch(const ConvK& k, hipStream_t stream) {
+    const int npad = (int)vqae::round_up(k.Cout, 32);
+    dim3 grid((unsigned)vqae::ceil_div(k.M, 128), (unsigned)vqae::ceil_div(npad, NT));
+    constexpr int lds_bytes = 2 * (128 + NT) * (KC + 4) * (int)sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)conv_mfma_kernel<NT, KC>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        attr_set = true;
+    }
+    conv_mfma_kernel<NT, KC><<<grid, 256, lds_bytes, stream>>>(k);
+    VQAE_LAUNCH_CHECK();
+    return VQAE_OK;
+}
+
+template <int NT>
+int launch_kc(const ConvK& k, int kc, hipStream_t stream) {
+    switch (kc) {
+        case 32: return launch<NT, 32>(k, stream);
+        case 16: return launch<NT, 16>(k, stream);
+        default: return launch<NT, 8>(k, stream);
+    }
+}
+
+}  // namespace
+
+extern "C" size_t vqae_conv_packed_floats(int cout, int cin, int ksize) {
+    // rows padded to a multiple of 128 so every N tile (32/64/128 wide) reads in-bounds rows
+    return (size_t)vqae::round_up(cout, 128) * ksize * ksize * cin;
+}
+
+extern "C" int vqae_conv_pack_weight_f32(const float* w, int cout, int cin, int ks, float* packed, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VQAE_REQUIRE(w && packed, VQAE_ERR_INVALID, "pack_weight: null pointer");
+    VQAE_REQUIRE(ks >= 1 && ks <= 3 && cin >= 1 && cout >= 1, VQAE_ERR_INVALID, "pack_weight: bad shape");
+    const int npad = (int)vqae::round_up(cout, 128);
+    const int64_t tot = (int64_t)npad * ks * ks * cin;
+    pack_weight_kernel<<<(unsigned)vqae::ceil_div(tot, 256), 256, 0, stream>>>(w, cout, cin, ks, npad, packed);
+    VQAE_LAUNCH_CHECK();
+    return VQAE_OK;
+}
+
+extern "C" int vqae_conv2d_f32(const vqae_conv_args* a, const float* x, const float* w, const float* bias_vec,
+                               const float* residual, float* y, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VQAE_REQUIRE(a && x && w && y, VQAE_ERR_INVALID, "conv2d: null pointer");
+    VQAE_REQUIRE(a->cin % 8 == 0 && a->cin >= 8, VQAE_ERR_UNSUPPORTED,
+                 "conv2d: cin %d must be a multiple of 8 (use vqae_conv3x3_direct_f32 for stems)", a->cin);
+    VQAE_REQUIRE(a->ksize >= 1 && a->ksize <= 3 && (a->stride == 1 || a->stride == 2) && a->pad >= 0 && a->pad <= 1,
+                 VQAE_ERR_UNSUPPORTED, "conv2d: unsupported geometry k%d s%d p%d", a->ksize, a->stride, a->pad);
+    VQAE_REQUIRE(a->batch >= 0 && a->in_h >= 1 && a->in_w >= 1 && a->cout >= 1, VQAE_ERR_INVALID, "conv2d: bad shape");
+    const int Ho = (a->in_h + 2 * a->pad - a->ksize) / a->stride + 1;
+    const int Wo = (a->in_w + 2 * a->pad - a->ksize) / a->stride + 1;
+    VQAE_REQUIRE(Ho >= 1 && Wo >= 1, VQAE_ERR_INVALID, "conv2d: empty output");
+    if (a->pad_mode == VQAE_PAD_CIRCULAR)
+        VQAE_REQUIRE(a->pad <= a->in_h && a->pad <= a->in_w, VQAE_ERR_INVALID, "conv2d: circular pad larger than input");
+    const int64_t M = (int64_t)a->batch * Ho * Wo;
+    VQAE_REQUIRE(M < (1ll << 31) - 256, VQAE_ERR_UNSUPPORTED, "conv2d: too many output pixels (%lld)", (long long)M);
+    if (M == 0) return VQAE_OK;
+
+    ConvK k;
+    k.x = x; k.w = w; k.bias_vec = bias_vec; k.residual = residual; k.y = y;
+    k.B = a->batch; k.H = a->in_h; k.W = a->in_w; k.Cin = a->cin; k.Cout = a->cout; k.Ho = Ho; k.Wo = Wo;
+    k.ks = a->ksize; k.stride = a->stride; k.pad = a->pad;
+    k.pad_mode = (a->pad == 0) ? VQAE_PAD_ZEROS : a->pad_mode;    // pad 0: the bounds test always passes
+    VQAE_REQUIRE(k.pad_mode == VQAE_PAD_ZEROS || k.pad_mode == VQAE_PAD_CIRCULAR, VQAE_ERR_INVALID,
+                 "conv2d: pad_mode %d", a->pad_mode);
+    k.M = (int)M; k.Ktot = a->ksize * a->ksize * a->cin;
+    const int kc = (a->cin % 32 == 0) ? 32 : (a->cin % 16 == 0) ? 16 : 8;
+    k.n_chunks = a->cin / kc;
+    k.n_steps = a->ksize * a->ksize * k.n_chunks;
+    k.pre_mode = a->pre_mode; k.pre_a = a->pre_a; k.pre_b = a->pre_b;
+    k.has_scale = a->has_scale; k.has_bias_s = a->has_bias_s; k.has_act = a->has_act;
+    k.scale = a->scale; k.bias_s = a->bias_s; k.act_a = a->act_a; k.act_b = a->act_b;
+
+    if (a->cout <= 32) return launch_kc<32>(k, kc, stream);
+    if (a->cout <= 64) return launch_kc<64>(k, kc, stream);
+    return launch_kc<128>(k, kc, stream);
+}

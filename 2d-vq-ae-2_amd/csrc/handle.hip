@@ -1,0 +1,568 @@
+// Whole-model handle: the native runtime that walks the Fixup block sequence of
+// Encoder.forward / Decoder.forward / VQAE.forward (reference vq_ae/model.py:189-217, 274-291, 41-48)
+// and launches the HIP kernels of this library on one stream.  Weights arrive as named host tensors in
+// the reference's state-dict naming and are repacked once into the MFMA kernel's
+// [cout_pad][tap*cin] layout; activations stay NHWC fp32 in four rotating HBM buffers owned by the
+// handle (X = residual stream, P/Q/R = block temporaries).
+#include "common.h"
+
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace vqae {
+char* last_error_buf() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+int conv3x3_direct(const void* x, int x_kind, const float* mean255, const float* inv_std255, const float* w,
+                   const float* bias, int B, int H, int W, int cin, int cout, float* y, int y_nchw,
+                   hipStream_t stream);
+}  // namespace vqae
+
+extern "C" const char* vqae_last_error(void) { return vqae::last_error_buf(); }
+extern "C" const char* vqae_build_info(void) { return "gfx950;fp32-mfma;" __DATE__; }
+
+namespace {
+
+enum { MODE_SAME = 0, MODE_DOWN = 1, MODE_UP = 2 };
+
+struct Block {
+    int mode, cin, cout, br;
+    float b1a, b1b, b2a, b2b, b3a, b3b, b4, scale, b1c, b1d;
+    float *w1, *w2, *w3, *wskip;          // packed, device
+};
+
+// CAMELYON16 normalisation (conf/transforms/camelyon16_transforms.yaml:15-23), x255
+const float kMean255[3] = {0.7279f * 255.0f, 0.5955f * 255.0f, 0.7762f * 255.0f};
+const float kInv255[3] = {1.0f / (0.2419f * 255.0f), 1.0f / (0.3083f * 255.0f), 1.0f / (0.1741f * 255.0f)};
+
+}  // namespace
+
+struct vqae_handle {
+    vqae_config cfg;
+    int C = 0, D = 0, K = 0;
+    std::vector<Block> enc, dec;
+    float *stem_w = nullptr, *stem_b = nullptr, *ostem_w = nullptr, *ostem_b = nullptr;
+    float *embed = nullptr;
+    float *pin_w = nullptr, *pin_b = nullptr, *pout_w = nullptr, *pout_b = nullptr;
+    std::vector<void*> owned;              // every hipMalloc of the weight set
+    // workspace
+    float* buf[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t buf_floats = 0;
+    void* vq_ws = nullptr;
+    size_t vq_ws_bytes = 0;
+    float* loss_scratch = nullptr;
+    bool has_encoder = false, has_decoder = false;
+    void* idx_scratch = nullptr;           // indices nobody asked for (vqae_forward with idx == NULL)
+    size_t idx_scratch_bytes = 0;
+};
+
+namespace {
+
+using TensorMap = std::unordered_map<std::string, const vqae_tensor*>;
+
+int find(const TensorMap& tm, const std::string& name, int64_t numel, const float** out) {
+    auto it = tm.find(name);
+    if (it == tm.end()) return vqae::fail(VQAE_ERR_NOT_FOUND, "missing tensor '%s'", name.c_str());
+    if (it->second->numel != numel)
+        return vqae::fail(VQAE_ERR_INVALID, "tensor '%s' has %lld elements, expected %lld", name.c_str(),
+                          (long long)it->second->numel, (long long)numel);
+    *out = it->second->data;
+    return VQAE_OK;
+}
+
+int dev_alloc(vqae_handle* h, size_t bytes, void** out) {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess)
+        return vqae::fail(VQAE_ERR_NOMEM, "hipMalloc of %zu bytes failed", bytes);
+    h->owned.push_back(p);
+    *out = p;
+    return VQAE_OK;
+}
+
+int upload(vqae_handle* h, const float* host, int64_t numel, float** out) {
+    void* p;
+    int rc = dev_alloc(h, (size_t)numel * 4, &p);
+    if (rc) return rc;
+    VQAE_HIP_CHECK(hipMemcpy(p, host, (size_t)numel * 4, hipMemcpyHostToDevice));
+    *out = (float*)p;
+    return VQAE_OK;
+}
+
+int upload_packed(vqae_handle* h, const float* host, int cout, int cin, int ks, float** out) {
+    float* raw = nullptr;
+    void* tmp = nullptr;
+    const int64_t numel = (int64_t)cout * cin * ks * ks;
+    if (hipMalloc(&tmp, (size_t)numel * 4) != hipSuccess) return vqae::fail(VQAE_ERR_NOMEM, "hipMalloc failed");
+    raw = (float*)tmp;
+    hipError_t e = hipMemcpy(raw, host, (size_t)numel * 4, hipMemcpyHostToDevice);
+    void* packed = nullptr;
+    int rc = (e == hipSuccess) ? dev_alloc(h, vqae_conv_packed_floats(cout, cin, ks) * 4, &packed)
+                               : vqae::fail(VQAE_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(e));
+    if (rc == VQAE_OK) rc = vqae_conv_pack_weight_f32(raw, cout, cin, ks, (float*)packed, nullptr);
+    if (rc == VQAE_OK && hipDeviceSynchronize() != hipSuccess) rc = vqae::fail(VQAE_ERR_HIP, "pack sync failed");
+    (void)hipFree(tmp);
+    *out = (float*)packed;
+    return rc;
+}
+
+int scalar(const TensorMap& tm, const std::string& name, float* out) {
+    const float* p;
+    int rc = find(tm, name, 1, &p);
+    if (rc) return rc;
+    *out = p[0];
+    return VQAE_OK;
+}
+
+int load_block(vqae_handle* h, const TensorMap& tm, const std::string& pre, int mode, int cin, int cout, Block* b) {
+    b->mode = mode; b->cin = cin; b->cout = cout; b->br = cin > cout ? cin : cout;   // conv_block.py:151-155
+    b->w1 = b->w2 = b->w3 = b->wskip = nullptr;
+    b->b1c = b->b1d = 0.f;
+    int rc;
+#define S_(field, nm) if ((rc = scalar(tm, pre + "." nm, &b->field))) return rc;
+    S_(b1a, "bias1a") S_(b1b, "bias1b") S_(b2a, "bias2a") S_(b2b, "bias2b") S_(b3a, "bias3a") S_(b3b, "bias3b")
+    S_(b4, "bias4") S_(scale, "scale")
+    const int k2 = mode == MODE_SAME ? 3 : (mode == MODE_DOWN ? 2 : 1);
+    const float* p;
+    if ((rc = find(tm, pre + ".branch_conv1.weight", (int64_t)b->br * cin, &p))) return rc;
+    if ((rc = upload_packed(h, p, b->br, cin, 1, &b->w1))) return rc;
+    if ((rc = find(tm, pre + ".branch_conv2.weight", (int64_t)b->br * b->br * k2 * k2, &p))) return rc;
+    if ((rc = upload_packed(h, p, b->br, b->br, k2, &b->w2))) return rc;
+    if ((rc = find(tm, pre + ".branch_conv3.weight", (int64_t)cout * b->br, &p))) return rc;
+    if ((rc = upload_packed(h, p, cout, b->br, 1, &b->w3))) return rc;
+    if (mode != MODE_SAME) {
+        S_(b1c, "bias1c") S_(b1d, "bias1d")
+        const int ks = mode == MODE_DOWN ? 2 : 1;
+        if ((rc = find(tm, pre + ".skip_conv.weight", (int64_t)cout * cin * ks * ks, &p))) return rc;
+        if ((rc = upload_packed(h, p, cout, cin, ks, &b->wskip))) return rc;
+    }
+#undef S_
+    return VQAE_OK;
+}
+
+// ---- one conv launch --------------------------------------------------------------------------
+struct ConvCall {
+    vqae_conv_args a;
+    ConvCall(int B, int H, int W, int cin, int cout, int ks, int stride, int pad, int pad_mode) {
+        memset(&a, 0, sizeof(a));
+        a.batch = B; a.in_h = H; a.in_w = W; a.cin = cin; a.cout = cout;
+        a.ksize = ks; a.stride = stride; a.pad = pad; a.pad_mode = pad_mode;
+    }
+    ConvCall& pre(int mode, float pa, float pb) { a.pre_mode = mode; a.pre_a = pa; a.pre_b = pb; return *this; }
+    ConvCall& act(float aa, float ab) { a.has_act = 1; a.act_a = aa; a.act_b = ab; return *this; }
+    ConvCall& scale_bias(float s, float b) { a.has_scale = 1; a.scale = s; a.bias_s = b; return *this; }
+    ConvCall& bias(float b) { a.has_bias_s = 1; a.bias_s = b; return *this; }
+};
+
+// PreActFixupResBlock.forward (conv_block.py:196-216) on NHWC buffers.  X holds the input and, on
+// return, buf[0] holds the output (buffers are swapped for down/up).
+int run_block(vqae_handle* h, const Block& b, int B, int& H, int& W, hipStream_t st) {
+    float *X = h->buf[0], *P = h->buf[1], *Q = h->buf[2], *R = h->buf[3];
+    int rc;
+    if (b.mode == MODE_SAME) {
+        ConvCall c1(B, H, W, b.cin, b.br, 1, 1, 0, VQAE_PAD_NONE);
+        c1.pre(VQAE_PRE_BIAS_ELU_BIAS, b.b1a, b.b1b).act(b.b2a, b.b2b);
+        if ((rc = vqae_conv2d_f32(&c1.a, X, b.w1, nullptr, nullptr, P, st))) return rc;
+        ConvCall c2(B, H, W, b.br, b.br, 3, 1, 1, VQAE_PAD_CIRCULAR);
+        c2.act(b.b3a, b.b3b);
+        if ((rc = vqae_conv2d_f32(&c2.a, P, b.w2, nullptr, nullptr, Q, st))) return rc;
+        ConvCall c3(B, H, W, b.br, b.cout, 1, 1, 0, VQAE_PAD_NONE);
+        c3.scale_bias(b.scale, b.b4);
+        return vqae_conv2d_f32(&c3.a, Q, b.w3, nullptr, X, X, st);          // + inp, in place
+    }
+    if (b.mode == MODE_DOWN) {
+        ConvCall sk(B, H, W, b.cin, b.cout, 2, 2, 0, VQAE_PAD_NONE);         // skip_conv(inp + bias1c) + bias1d
+        sk.pre(VQAE_PRE_BIAS, b.b1c, 0.f).bias(b.b1d);
+        if ((rc = vqae_conv2d_f32(&sk.a, X, b.wskip, nullptr, nullptr, R, st))) return rc;
+        ConvCall c1(B, H, W, b.cin, b.br, 1, 1, 0, VQAE_PAD_NONE);
+        c1.pre(VQAE_PRE_BIAS_ELU_BIAS, b.b1a, b.b1b).act(b.b2a, b.b2b);
+        if ((rc = vqae_conv2d_f32(&c1.a, X, b.w1, nullptr, nullptr, P, st))) return rc;
+        ConvCall c2(B, H, W, b.br, b.br, 2, 2, 0, VQAE_PAD_NONE);
+        c2.act(b.b3a, b.b3b);
+        if ((rc = vqae_conv2d_f32(&c2.a, P, b.w2, nullptr, nullptr, Q, st))) return rc;
+        H /= 2; W /= 2;
+        ConvCall c3(B, H, W, b.br, b.cout, 1, 1, 0, VQAE_PAD_NONE);
+        c3.scale_bias(b.scale, b.b4);
+        if ((rc = vqae_conv2d_f32(&c3.a, Q, b.w3, nullptr, R, R, st))) return rc;
+        std::swap(h->buf[0], h->buf[3]);
+        return VQAE_OK;
+    }
+    // MODE_UP: ResizeConv2D = conv1x1(bicubic_x2(.)) (layers/conv.py:10-11)
+    if ((rc = vqae_bicubic_up2_f32(X, B, H, W, b.cin, b.b1c, P, st))) return rc;               // up(inp + bias1c)
+    ConvCall sk(B, 2 * H, 2 * W, b.cin, b.cout, 1, 1, 0, VQAE_PAD_NONE);
+    sk.bias(b.b1d);
+    if ((rc = vqae_conv2d_f32(&sk.a, P, b.wskip, nullptr, nullptr, R, st))) return rc;
+    ConvCall c1(B, H, W, b.cin, b.br, 1, 1, 0, VQAE_PAD_NONE);
+    c1.pre(VQAE_PRE_BIAS_ELU_BIAS, b.b1a, b.b1b).act(b.b2a, b.b2b);
+    if ((rc = vqae_conv2d_f32(&c1.a, X, b.w1, nullptr, nullptr, Q, st))) return rc;
+    if ((rc = vqae_bicubic_up2_f32(Q, B, H, W, b.br, 0.f, P, st))) return rc;
+    H *= 2; W *= 2;
+    ConvCall c2(B, H, W, b.br, b.br, 1, 1, 0, VQAE_PAD_NONE);
+    c2.act(b.b3a, b.b3b);
+    if ((rc = vqae_conv2d_f32(&c2.a, P, b.w2, nullptr, nullptr, Q, st))) return rc;
+    ConvCall c3(B, H, W, b.br, b.cout, 1, 1, 0, VQAE_PAD_NONE);
+    c3.scale_bias(b.scale, b.b4);
+    if ((rc = vqae_conv2d_f32(&c3.a, Q, b.w3, nullptr, R, R, st))) return rc;
+    std::swap(h->buf[0], h->buf[3]);
+    return VQAE_OK;
+}
+
+size_t max_floats_per_patch(const vqae_handle* h, int in_h, int in_w) {
+    // largest NHWC intermediate: the bicubic-upsampled 2C tensor of the last up block / conv1 of the
+    // first down block (both 2*stem channels at full resolution), or the code tensor.
+    size_t full = (size_t)in_h * in_w * (size_t)(2 * h->cfg.stem);
+    size_t lat = (size_t)(in_h >> h->cfg.n_down) * (in_w >> h->cfg.n_down) * (size_t)h->C;
+    return full > lat ? full : lat;
+}
+
+int ensure_workspace(vqae_handle* h, int B, int in_h, int in_w) {
+    const size_t need = max_floats_per_patch(h, in_h, in_w) * (size_t)(B > 0 ? B : 1);
+    if (need > h->buf_floats) {
+        VQAE_HIP_CHECK(hipDeviceSynchronize());
+        for (int i = 0; i < 4; ++i) {
+            if (h->buf[i]) (void)hipFree(h->buf[i]);
+            h->buf[i] = nullptr;
+        }
+        h->buf_floats = 0;
+        for (int i = 0; i < 4; ++i)
+            if (hipMalloc((void**)&h->buf[i], need * sizeof(float)) != hipSuccess)
+                return vqae::fail(VQAE_ERR_NOMEM, "workspace hipMalloc of %zu bytes failed", need * sizeof(float));
+        h->buf_floats = need;
+    }
+    const int64_t rows = (int64_t)B * (in_h >> h->cfg.n_down) * (in_w >> h->cfg.n_down);
+    const size_t vq_need = vqae_vq_workspace_bytes(rows, h->K, h->D);
+    if (vq_need > h->vq_ws_bytes) {
+        VQAE_HIP_CHECK(hipDeviceSynchronize());
+        if (h->vq_ws) (void)hipFree(h->vq_ws);
+        h->vq_ws = nullptr; h->vq_ws_bytes = 0;
+        if (hipMalloc(&h->vq_ws, vq_need) != hipSuccess)
+            return vqae::fail(VQAE_ERR_NOMEM, "vq workspace hipMalloc of %zu bytes failed", vq_need);
+        h->vq_ws_bytes = vq_need;
+    }
+    const size_t idx_need = (size_t)vqae::round_up(rows * 4, 256);
+    if (idx_need > h->idx_scratch_bytes) {
+        VQAE_HIP_CHECK(hipDeviceSynchronize());
+        if (h->idx_scratch) (void)hipFree(h->idx_scratch);
+        h->idx_scratch = nullptr; h->idx_scratch_bytes = 0;
+        if (hipMalloc(&h->idx_scratch, idx_need) != hipSuccess)
+            return vqae::fail(VQAE_ERR_NOMEM, "idx scratch hipMalloc of %zu bytes failed", idx_need);
+        h->idx_scratch_bytes = idx_need;
+    }
+    return VQAE_OK;
+}
+
+int check_geometry(const vqae_handle* h, int B, int in_h, int in_w) {
+    const int f = 1 << h->cfg.n_down;
+    VQAE_REQUIRE(B >= 0, VQAE_ERR_INVALID, "negative batch");
+    VQAE_REQUIRE(in_h >= f && in_w >= f && in_h % f == 0 && in_w % f == 0, VQAE_ERR_INVALID,
+                 "input %dx%d must be a positive multiple of 2^n_down = %d", in_h, in_w, f);
+    return VQAE_OK;
+}
+
+// in_stem + down blocks + pre_enc blocks: x -> z in buf[0]  (model.py:198-208)
+int run_encoder_convs(vqae_handle* h, const void* x, int x_kind, int B, int in_h, int in_w, int* zh, int* zw,
+                      hipStream_t st) {
+    int rc;
+    if ((rc = vqae::conv3x3_direct(x, x_kind, kMean255, kInv255, h->stem_w, h->stem_b, B, in_h, in_w,
+                                   h->cfg.in_channels, h->cfg.stem, h->buf[0], 0, st))) return rc;
+    int H = in_h, W = in_w;
+    for (const Block& b : h->enc)
+        if ((rc = run_block(h, b, B, H, W, st))) return rc;
+    *zh = H; *zw = W;
+    return VQAE_OK;
+}
+
+// VQ level: z (buf[0]) -> q (NHWC, C channels) in buf[0]; idx/loss to the caller.
+// Plain: EMAVectorQuantizer.forward (vq.py:96-154).  Projected: proj_out(VQ(proj_in(z))) (vq.py:190-192).
+int run_vq(vqae_handle* h, int B, int zh, int zw, void* idx, int idx_dtype, float* loss, hipStream_t st) {
+    const int64_t rows = (int64_t)B * zh * zw;
+    int rc;
+    if (h->cfg.projection_dim > 0) {
+        ConvCall pin(B, zh, zw, h->C, h->D, 1, 1, 0, VQAE_PAD_NONE);
+        if ((rc = vqae_conv2d_f32(&pin.a, h->buf[0], h->pin_w, h->pin_b, nullptr, h->buf[1], st))) return rc;
+        if ((rc = vqae_vq_forward_f32(h->buf[1], h->embed, rows, h->K, h->D, h->cfg.commitment_cost, idx, idx_dtype,
+                                      h->buf[2], loss, nullptr, h->vq_ws, st))) return rc;
+        ConvCall pout(B, zh, zw, h->D, h->C, 1, 1, 0, VQAE_PAD_NONE);
+        return vqae_conv2d_f32(&pout.a, h->buf[2], h->pout_w, h->pout_b, nullptr, h->buf[0], st);
+    }
+    if ((rc = vqae_vq_forward_f32(h->buf[0], h->embed, rows, h->K, h->D, h->cfg.commitment_cost, idx, idx_dtype,
+                                  h->buf[1], loss, nullptr, h->vq_ws, st))) return rc;
+    std::swap(h->buf[0], h->buf[1]);
+    return VQAE_OK;
+}
+
+// post_enc blocks + up blocks + out_stem: q in buf[0] -> out (model.py:278-291)
+int run_decoder_convs(vqae_handle* h, int B, int qh, int qw, int layout, float* out, hipStream_t st) {
+    int H = qh, W = qw, rc;
+    for (const Block& b : h->dec)
+        if ((rc = run_block(h, b, B, H, W, st))) return rc;
+    return vqae::conv3x3_direct(h->buf[0], 0, nullptr, nullptr, h->ostem_w, h->ostem_b, B, H, W, h->cfg.stem,
+                                h->cfg.in_channels, out, layout == VQAE_LAYOUT_NCHW ? 1 : 0, st);
+}
+
+int export_q(vqae_handle* h, int B, int zh, int zw, int layout, float* q, hipStream_t st) {
+    if (!q) return VQAE_OK;
+    if (layout == VQAE_LAYOUT_NCHW) return vqae_nhwc_to_nchw_f32(h->buf[0], B, h->C, zh, zw, q, st);
+    VQAE_HIP_CHECK(hipMemcpyAsync(q, h->buf[0], (size_t)B * zh * zw * h->C * 4, hipMemcpyDeviceToDevice, st));
+    return VQAE_OK;
+}
+
+}  // namespace
+
+extern "C" int vqae_create(const vqae_config* cfg, const vqae_tensor* tensors, int n_tensors, vqae_handle** out) {
+    VQAE_REQUIRE(cfg && tensors && out, VQAE_ERR_INVALID, "vqae_create: null pointer");
+    VQAE_REQUIRE(cfg->in_channels == 3, VQAE_ERR_UNSUPPORTED, "in_channels %d (only 3)", cfg->in_channels);
+    VQAE_REQUIRE(cfg->stem >= 4 && cfg->stem % 4 == 0 && cfg->stem <= 64, VQAE_ERR_UNSUPPORTED, "stem %d", cfg->stem);
+    VQAE_REQUIRE(cfg->stem % 8 == 0, VQAE_ERR_UNSUPPORTED, "stem %d must be a multiple of 8", cfg->stem);
+    VQAE_REQUIRE(cfg->n_down >= 1 && cfg->n_down <= 6 && cfg->n_pre >= 0 && cfg->n_post >= 0 && cfg->n_enc >= 0,
+                 VQAE_ERR_INVALID, "bad depth parameters");
+    VQAE_REQUIRE(cfg->num_embeddings >= 1 && cfg->num_embeddings <= 65536, VQAE_ERR_UNSUPPORTED, "num_embeddings %d",
+                 cfg->num_embeddings);
+    VQAE_REQUIRE(cfg->projection_dim == 0 || (cfg->projection_dim % 8 == 0), VQAE_ERR_UNSUPPORTED,
+                 "projection_dim %d must be 0 or a multiple of 8", cfg->projection_dim);
+    TensorMap tm;
+    for (int i = 0; i < n_tensors; ++i) tm[tensors[i].name] = &tensors[i];
+
+    vqae_handle* h = new vqae_handle();
+    h->cfg = *cfg;
+    h->C = cfg->stem << cfg->n_down;
+    h->D = cfg->projection_dim > 0 ? cfg->projection_dim : h->C;
+    h->K = cfg->num_embeddings;
+    int rc = VQAE_OK;
+    const float* p;
+    auto bail = [&](int code) { vqae_destroy(h); return code; };
+
+    const bool has_enc = tm.count("encoder.in_stem.weight") > 0;
+    const bool has_dec = tm.count("decoder.out_stem.weight") > 0;
+    if (!has_enc && !has_dec) return bail(vqae::fail(VQAE_ERR_NOT_FOUND, "neither encoder.* nor decoder.* tensors given"));
+    h->has_encoder = has_enc;
+    h->has_decoder = has_dec;
+    int c = cfg->stem << cfg->n_down;
+    const std::string vq = "encoder.vq_layers.0.";
+
+    if (has_enc) {
+        if ((rc = find(tm, "encoder.in_stem.weight", (int64_t)cfg->stem * 3 * 9, &p)) || (rc = upload(h, p, (int64_t)cfg->stem * 27, &h->stem_w))) return bail(rc);
+        if ((rc = find(tm, "encoder.in_stem.bias", cfg->stem, &p)) || (rc = upload(h, p, cfg->stem, &h->stem_b))) return bail(rc);
+        // encoder blocks: DownBlock levels (conv_block.py:35-47) then pre_enc (model.py:173-176)
+        c = cfg->stem;
+        for (int lvl = 0; lvl < cfg->n_down; ++lvl) {
+            const std::string base = "encoder.down_layers.0.layers." + std::to_string(lvl) + ".layers.";
+            int bi = 0;
+            Block b;
+            for (int i = 0; i < cfg->n_pre; ++i, ++bi) {
+                if ((rc = load_block(h, tm, base + std::to_string(bi), MODE_SAME, c, c, &b))) return bail(rc);
+                h->enc.push_back(b);
+            }
+            if ((rc = load_block(h, tm, base + std::to_string(bi), MODE_DOWN, c, 2 * c, &b))) return bail(rc);
+            h->enc.push_back(b); ++bi;
+            for (int i = 0; i < cfg->n_post; ++i, ++bi) {
+                if ((rc = load_block(h, tm, base + std::to_string(bi), MODE_SAME, 2 * c, 2 * c, &b))) return bail(rc);
+                h->enc.push_back(b);
+            }
+            c *= 2;
+        }
+        for (int i = 0; i < cfg->n_enc; ++i) {
+            Block b;
+            if ((rc = load_block(h, tm, "encoder.pre_enc_layers.0." + std::to_string(i), MODE_SAME, c, c, &b))) return bail(rc);
+            h->enc.push_back(b);
+        }
+    }
+    // VQ (codebook is required with an encoder, optional for decode-only handles)
+    if (has_enc || tm.count(vq + "embed")) {
+        if ((rc = find(tm, vq + "embed", (int64_t)h->K * h->D, &p)) || (rc = upload(h, p, (int64_t)h->K * h->D, &h->embed))) return bail(rc);
+        if (cfg->projection_dim > 0) {
+            if ((rc = find(tm, vq + "proj_in.weight", (int64_t)h->D * h->C, &p)) || (rc = upload_packed(h, p, h->D, h->C, 1, &h->pin_w))) return bail(rc);
+            if ((rc = find(tm, vq + "proj_in.bias", h->D, &p)) || (rc = upload(h, p, h->D, &h->pin_b))) return bail(rc);
+            if ((rc = find(tm, vq + "proj_out.weight", (int64_t)h->C * h->D, &p)) || (rc = upload_packed(h, p, h->C, h->D, 1, &h->pout_w))) return bail(rc);
+            if ((rc = find(tm, vq + "proj_out.bias", h->C, &p)) || (rc = upload(h, p, h->C, &h->pout_b))) return bail(rc);
+        }
+    }
+    if (has_dec) {
+        if ((rc = find(tm, "decoder.out_stem.weight", (int64_t)3 * cfg->stem * 9, &p)) || (rc = upload(h, p, (int64_t)cfg->stem * 27, &h->ostem_w))) return bail(rc);
+        if ((rc = find(tm, "decoder.out_stem.bias", 3, &p)) || (rc = upload(h, p, 3, &h->ostem_b))) return bail(rc);
+        // decoder blocks: post_enc then UpBlock levels (conv_block.py:72-88)
+        c = cfg->stem << cfg->n_down;
+        for (int i = 0; i < cfg->n_enc; ++i) {
+            Block b;
+            if ((rc = load_block(h, tm, "decoder.post_enc_layers.0." + std::to_string(i), MODE_SAME, c, c, &b))) return bail(rc);
+            h->dec.push_back(b);
+        }
+        for (int lvl = 0; lvl < cfg->n_down; ++lvl) {
+            const std::string base = "decoder.up_layers.0.layers." + std::to_string(lvl) + ".layers.";
+            int bi = 0;
+            Block b;
+            for (int i = 0; i < cfg->n_pre; ++i, ++bi) {
+                if ((rc = load_block(h, tm, base + std::to_string(bi), MODE_SAME, c, c, &b))) return bail(rc);
+                h->dec.push_back(b);
+            }
+            if ((rc = load_block(h, tm, base + std::to_string(bi), MODE_UP, c, c / 2, &b))) return bail(rc);
+            h->dec.push_back(b); ++bi;
+            for (int i = 0; i < cfg->n_post; ++i, ++bi) {
+                if ((rc = load_block(h, tm, base + std::to_string(bi), MODE_SAME, c / 2, c / 2, &b))) return bail(rc);
+                h->dec.push_back(b);
+            }
+            c /= 2;
+        }
+    }
+    void* ls = nullptr;
+    if ((rc = dev_alloc(h, 256, &ls))) return bail(rc);
+    h->loss_scratch = (float*)ls;
+    *out = h;
+    return VQAE_OK;
+}
+
+extern "C" void vqae_destroy(vqae_handle* h) {
+    if (!h) return;
+    (void)hipDeviceSynchronize();
+    for (void* p : h->owned) (void)hipFree(p);
+    for (int i = 0; i < 4; ++i)
+        if (h->buf[i]) (void)hipFree(h->buf[i]);
+    if (h->vq_ws) (void)hipFree(h->vq_ws);
+    if (h->idx_scratch) (void)hipFree(h->idx_scratch);
+    delete h;
+}
+
+extern "C" int vqae_reserve(vqae_handle* h, int max_batch, int in_h, int in_w) {
+    VQAE_REQUIRE(h, VQAE_ERR_INVALID, "null handle");
+    int rc = check_geometry(h, max_batch, in_h, in_w);
+    if (rc) return rc;
+    return ensure_workspace(h, max_batch, in_h, in_w);
+}
+
+extern "C" int vqae_set_codebook(vqae_handle* h, const float* embed_host) {
+    VQAE_REQUIRE(h && embed_host && h->embed, VQAE_ERR_INVALID, "set_codebook: null pointer / handle has no codebook");
+    VQAE_HIP_CHECK(hipDeviceSynchronize());
+    VQAE_HIP_CHECK(hipMemcpy(h->embed, embed_host, (size_t)h->K * h->D * 4, hipMemcpyHostToDevice));
+    return VQAE_OK;
+}
+
+static int encode_impl(vqae_handle* h, const void* x, int x_kind, int B, int in_h, int in_w, void* idx, int idx_dtype,
+                       float* q, int q_layout, float* loss, hipStream_t st) {
+    VQAE_REQUIRE(h && x && idx, VQAE_ERR_INVALID, "vqae_encode: null pointer");
+    VQAE_REQUIRE(h->has_encoder, VQAE_ERR_INVALID, "vqae_encode: handle was created without encoder.* tensors");
+    int rc = check_geometry(h, B, in_h, in_w);
+    if (rc) return rc;
+    if (B == 0) return VQAE_OK;
+    if ((rc = ensure_workspace(h, B, in_h, in_w))) return rc;
+    int zh, zw;
+    if ((rc = run_encoder_convs(h, x, x_kind, B, in_h, in_w, &zh, &zw, st))) return rc;
+    if ((rc = run_vq(h, B, zh, zw, idx, idx_dtype, loss, st))) return rc;
+    return export_q(h, B, zh, zw, q_layout, q, st);
+}
+
+extern "C" int vqae_encode(vqae_handle* h, const float* x, int B, int in_h, int in_w, int layout, void* idx,
+                           int idx_dtype, float* q, float* loss, void* stream) {
+    return encode_impl(h, x, layout == VQAE_LAYOUT_NCHW ? 1 : 0, B, in_h, in_w, idx, idx_dtype, q, layout, loss,
+                       (hipStream_t)stream);
+}
+
+extern "C" int vqae_encode_u8(vqae_handle* h, const uint8_t* x, int B, int in_h, int in_w, void* idx, int idx_dtype,
+                              float* q, int q_layout, float* loss, void* stream) {
+    return encode_impl(h, x, 2, B, in_h, in_w, idx, idx_dtype, q, q_layout, loss, (hipStream_t)stream);
+}
+
+extern "C" int vqae_encode_features(vqae_handle* h, const float* x, int B, int in_h, int in_w, int layout, float* z,
+                                    void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    VQAE_REQUIRE(h && x && z, VQAE_ERR_INVALID, "vqae_encode_features: null pointer");
+    VQAE_REQUIRE(h->has_encoder, VQAE_ERR_INVALID, "vqae_encode_features: handle has no encoder");
+    int rc = check_geometry(h, B, in_h, in_w);
+    if (rc) return rc;
+    if (B == 0) return VQAE_OK;
+    if ((rc = ensure_workspace(h, B, in_h, in_w))) return rc;
+    int zh, zw;
+    if ((rc = run_encoder_convs(h, x, layout == VQAE_LAYOUT_NCHW ? 1 : 0, B, in_h, in_w, &zh, &zw, st))) return rc;
+    if (h->cfg.projection_dim > 0) {
+        ConvCall pin(B, zh, zw, h->C, h->D, 1, 1, 0, VQAE_PAD_NONE);
+        return vqae_conv2d_f32(&pin.a, h->buf[0], h->pin_w, h->pin_b, nullptr, z, st);
+    }
+    VQAE_HIP_CHECK(hipMemcpyAsync(z, h->buf[0], (size_t)B * zh * zw * h->C * 4, hipMemcpyDeviceToDevice, st));
+    return VQAE_OK;
+}
+
+extern "C" int vqae_decode(vqae_handle* h, const float* q, int B, int qh, int qw, int layout, float* out, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    VQAE_REQUIRE(h && q && out, VQAE_ERR_INVALID, "vqae_decode: null pointer");
+    VQAE_REQUIRE(h->has_decoder, VQAE_ERR_INVALID, "vqae_decode: handle was created without decoder.* tensors");
+    VQAE_REQUIRE(B >= 0 && qh >= 1 && qw >= 1, VQAE_ERR_INVALID, "vqae_decode: bad shape");
+    if (B == 0) return VQAE_OK;
+    int rc;
+    if ((rc = ensure_workspace(h, B, qh << h->cfg.n_down, qw << h->cfg.n_down))) return rc;
+    if (layout == VQAE_LAYOUT_NCHW) {
+        if ((rc = vqae_nchw_to_nhwc_f32(q, B, h->C, qh, qw, h->buf[0], st))) return rc;
+    } else {
+        VQAE_HIP_CHECK(hipMemcpyAsync(h->buf[0], q, (size_t)B * qh * qw * h->C * 4, hipMemcpyDeviceToDevice, st));
+    }
+    return run_decoder_convs(h, B, qh, qw, layout, out, st);
+}
+
+extern "C" int vqae_decode_indices(vqae_handle* h, const void* idx, int idx_dtype, int B, int qh, int qw, int layout,
+                                   float* out, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    VQAE_REQUIRE(h && idx && out, VQAE_ERR_INVALID, "vqae_decode_indices: null pointer");
+    VQAE_REQUIRE(h->has_decoder && h->embed, VQAE_ERR_INVALID, "vqae_decode_indices: handle needs decoder.* tensors and a codebook");
+    VQAE_REQUIRE(B >= 0 && qh >= 1 && qw >= 1, VQAE_ERR_INVALID, "vqae_decode_indices: bad shape");
+    if (B == 0) return VQAE_OK;
+    int rc;
+    if ((rc = ensure_workspace(h, B, qh << h->cfg.n_down, qw << h->cfg.n_down))) return rc;
+    const int64_t rows = (int64_t)B * qh * qw;
+    if (h->cfg.projection_dim > 0) {
+        if ((rc = vqae_embed_code_f32(idx, idx_dtype, h->embed, rows, h->K, h->D, h->buf[1], st))) return rc;
+        ConvCall pout(B, qh, qw, h->D, h->C, 1, 1, 0, VQAE_PAD_NONE);
+        if ((rc = vqae_conv2d_f32(&pout.a, h->buf[1], h->pout_w, h->pout_b, nullptr, h->buf[0], st))) return rc;
+    } else {
+        if ((rc = vqae_embed_code_f32(idx, idx_dtype, h->embed, rows, h->K, h->D, h->buf[0], st))) return rc;
+    }
+    return run_decoder_convs(h, B, qh, qw, layout, out, st);
+}
+
+extern "C" int vqae_forward(vqae_handle* h, const float* x, int B, int in_h, int in_w, int layout, float* out, void* idx,
+                            int idx_dtype, float* loss, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    VQAE_REQUIRE(h && x && out, VQAE_ERR_INVALID, "vqae_forward: null pointer");
+    VQAE_REQUIRE(h->has_encoder && h->has_decoder, VQAE_ERR_INVALID, "vqae_forward: handle needs encoder.* and decoder.* tensors");
+    int rc = check_geometry(h, B, in_h, in_w);
+    if (rc) return rc;
+    if (B == 0) return VQAE_OK;
+    if ((rc = ensure_workspace(h, B, in_h, in_w))) return rc;
+    int zh, zw;
+    if ((rc = run_encoder_convs(h, x, layout == VQAE_LAYOUT_NCHW ? 1 : 0, B, in_h, in_w, &zh, &zw, st))) return rc;
+    // idx is optional here
+    void* idx_out = idx;
+    int dt = idx_dtype;
+    if (!idx_out) { idx_out = h->idx_scratch; dt = VQAE_IDX_I32; }
+    if ((rc = run_vq(h, B, zh, zw, idx_out, dt, loss ? loss : h->loss_scratch, st))) return rc;
+    return run_decoder_convs(h, B, zh, zw, layout, out, st);
+}
+
+extern "C" double vqae_flops_per_patch(const vqae_handle* h, int in_h, int in_w, int encoder, int decoder) {
+    if (!h) return 0.0;
+    double fl = 0.0;
+    auto blocks = [&](const std::vector<Block>& v, double H, double W) {
+        for (const Block& b : v) {
+            if (b.mode == MODE_SAME) {
+                fl += 2.0 * H * W * ((double)b.cin * b.br + 9.0 * b.br * b.br + (double)b.br * b.cout);
+            } else if (b.mode == MODE_DOWN) {
+                fl += 2.0 * H * W * (double)b.cin * b.br;                                   // conv1 @ HxW
+                H /= 2; W /= 2;
+                fl += 2.0 * H * W * (4.0 * b.br * b.br + (double)b.br * b.cout + 4.0 * b.cin * b.cout);
+            } else {
+                fl += 2.0 * H * W * (double)b.cin * b.br;                                   // conv1 @ low res
+                H *= 2; W *= 2;
+                fl += 2.0 * H * W * ((double)b.br * b.br + (double)b.br * b.cout + (double)b.cin * b.cout);
+            }
+        }
+        return std::pair<double, double>(H, W);
+    };
+    if (encoder) {
+        fl += 2.0 * in_h * in_w * 27.0 * h->cfg.stem;
+        auto hw = blocks(h->enc, in_h, in_w);
+        if (h->cfg.projection_dim > 0) fl += 2.0 * hw.first * hw.second * 2.0 * h->C * h->D;
+    }
+    if (decoder) {
+        blocks(h->dec, in_h >> h->cfg.n_down, in_w >> h->cfg.n_down);
+        fl += 2.0 * in_h * in_w * 27.0 * h->cfg.stem;
+    }
+    return fl;
+}

@@ -1,0 +1,301 @@
+// HBM-bound helper kernels of the VQ-AE hot path (gfx950): the 3-channel stems, bicubic x2,
+// boundary layout shuffles, label max-pool and slide-grid stitching.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Direct 3x3 / stride 1 / zero-pad conv + per-channel bias: `in_stem` (3 -> C0, reference
+// vq_ae/model.py:198, conv2d.yaml: bias True, padding_mode zeros) and `out_stem` (C0 -> 3, model.py:291).
+// One thread per output pixel, weights broadcast from LDS.  4 FLOP/B: HBM-bound.
+// x_kind: 0 fp32 NHWC, 1 fp32 NCHW, 2 uint8 NHWC normalised on the fly
+//   ((u - mean255[c]) * inv_std255[c]: albumentations Normalize, camelyon16_transforms.yaml:15-23).
+// ------------------------------------------------------------------------------------------------
+struct Norm3 { float mean[4]; float inv[4]; };
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256)
+void conv3x3_direct_kernel(const void* __restrict__ xin, int x_kind, Norm3 nrm, const float* __restrict__ w,
+                           const float* __restrict__ bias, int B, int H, int W, float* __restrict__ y, int y_nchw) {
+    __shared__ float ws[9 * CIN * COUT + COUT];          // [tap][ci][co], then bias
+    for (int i = threadIdx.x; i < 9 * CIN * COUT; i += 256) {
+        const int co = i % COUT, ci = (i / COUT) % CIN, tap = i / (COUT * CIN);
+        ws[i] = w[((int64_t)co * CIN + ci) * 9 + tap];   // PyTorch [co][ci][kh][kw]
+    }
+    for (int i = threadIdx.x; i < COUT; i += 256) ws[9 * CIN * COUT + i] = bias[i];
+    __syncthreads();
+
+    const int64_t npix = (int64_t)B * H * W;
+    const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= npix) return;
+    const int hw = H * W;
+    const int b = (int)(pix / hw), rem = (int)(pix - (int64_t)b * hw);
+    const int oy = rem / W, ox = rem - oy * W;
+
+    float acc[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = ws[9 * CIN * COUT + co];
+
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int iy = oy + dy - 1;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int ix = ox + dx - 1;
+            if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+            const int tap = dy * 3 + dx;
+            float xv[CIN];
+            if (x_kind == 0) {
+                const float* src = (const float*)xin + ((int64_t)b * hw + (int64_t)iy * W + ix) * CIN;
+                if constexpr (CIN % 4 == 0) {
+#pragma unroll
+                    for (int c = 0; c < CIN; c += 4) {
+                        const float4 v = *reinterpret_cast<const float4*>(src + c);
+                        xv[c] = v.x; xv[c + 1] = v.y; xv[c + 2] = v.z; xv[c + 3] = v.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < CIN; ++c) xv[c] = src[c];
+                }
+            } else if (x_kind == 1) {
+#pragma unroll
+                for (int c = 0; c < CIN; ++c)
+                    xv[c] = ((const float*)xin)[((int64_t)b * CIN + c) * hw + (int64_t)iy * W + ix];
+            } else {
+                const uint8_t* src = (const uint8_t*)xin + ((int64_t)b * hw + (int64_t)iy * W + ix) * CIN;
+#pragma unroll
+                for (int c = 0; c < CIN; ++c) xv[c] = ((float)src[c] - nrm.mean[c & 3]) * nrm.inv[c & 3];
+            }
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) {
+                const float* wr = ws + (tap * CIN + c) * COUT;
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) acc[co] = __builtin_fmaf(xv[c], wr[co], acc[co]);
+            }
+        }
+    }
+    if (y_nchw) {
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) y[((int64_t)b * COUT + co) * hw + rem] = acc[co];
+    } else {
+        float* dst = y + pix * COUT;
+        if constexpr (COUT % 4 == 0) {
+#pragma unroll
+            for (int co = 0; co < COUT; co += 4)
+                *reinterpret_cast<float4*>(dst + co) = make_float4(acc[co], acc[co + 1], acc[co + 2], acc[co + 3]);
+        } else {
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) dst[co] = acc[co];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bicubic x2 (A = -0.75, align_corners = False, clamped indices): nn.Upsample in ResizeConv2D
+// (reference vq_ae/layers/conv.py:8).  For scale 2 the source offset is .75 (even outputs, taps at
+// i-2..i+1) or .25 (odd outputs, taps at i-1..i+2) with i = o >> 1; out = sum_i wy_i * (sum_j wx_j * v_ij),
+// both sums left to right, unfused (oracle: bicubic_up2_explicit).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void bicubic_up2_kernel(const float4* __restrict__ x, int B, int H, int W, int C4, float pre_bias,
+                        float4* __restrict__ y) {
+    const float w75[4] = {-0.03515625f, 0.26171875f, 0.87890625f, -0.10546875f};
+    const float w25[4] = {-0.10546875f, 0.87890625f, 0.26171875f, -0.03515625f};
+    const int OH = 2 * H, OW = 2 * W;
+    const int64_t total = (int64_t)B * OH * OW * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        int64_t p = i / C4;
+        const int ox = (int)(p % OW); p /= OW;
+        const int oy = (int)(p % OH);
+        const int b = (int)(p / OH);
+        const int by = (oy >> 1) - ((oy & 1) ? 1 : 2);
+        const int bx = (ox >> 1) - ((ox & 1) ? 1 : 2);
+        const float* wy = (oy & 1) ? w25 : w75;
+        const float* wx = (ox & 1) ? w25 : w75;
+        int xs[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { int v = bx + j; xs[j] = v < 0 ? 0 : (v > W - 1 ? W - 1 : v); }
+        float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int yy = by + r; yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
+            const float4* row = x + ((int64_t)b * H + yy) * W * C4 + c4;
+            float4 in;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float4 v = row[(int64_t)xs[j] * C4];
+                v.x += pre_bias; v.y += pre_bias; v.z += pre_bias; v.w += pre_bias;
+                if (j == 0) { in.x = v.x * wx[0]; in.y = v.y * wx[0]; in.z = v.z * wx[0]; in.w = v.w * wx[0]; }
+                else { in.x = in.x + v.x * wx[j]; in.y = in.y + v.y * wx[j]; in.z = in.z + v.z * wx[j]; in.w = in.w + v.w * wx[j]; }
+            }
+            if (r == 0) { out.x = in.x * wy[0]; out.y = in.y * wy[0]; out.z = in.z * wy[0]; out.w = in.w * wy[0]; }
+            else { out.x = out.x + in.x * wy[r]; out.y = out.y + in.y * wy[r]; out.z = out.z + in.z * wy[r]; out.w = out.w + in.w * wy[r]; }
+        }
+        y[i] = out;
+    }
+}
+
+// Batched 2-D transpose: in [B][R][S] -> out [B][S][R]  (NCHW <-> NHWC with R/S = C / H*W).
+__global__ __launch_bounds__(256)
+void transpose_kernel(const float* __restrict__ in, int R, int S, float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int64_t base = (int64_t)blockIdx.z * R * S;
+    const int s0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) {
+        const int r = r0 + ty + j, s = s0 + tx;
+        if (r < R && s < S) tile[ty + j][tx] = in[base + (int64_t)r * S + s];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) {
+        const int s = s0 + ty + j, r = r0 + tx;
+        if (r < R && s < S) out[base + (int64_t)s * R + r] = tile[tx][ty + j];
+    }
+}
+
+__global__ __launch_bounds__(256)
+void label_maxpool_kernel(const uint8_t* __restrict__ lab, int B, int H, int W, int O, uint8_t* __restrict__ y) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)B * O * O) return;
+    const int ox = (int)(i % O), oy = (int)((i / O) % O), b = (int)(i / ((int64_t)O * O));
+    // adaptive pooling windows: [floor(o*H/O), ceil((o+1)*H/O))
+    const int y0 = (oy * H) / O, y1 = ((oy + 1) * H + O - 1) / O;
+    const int x0 = (ox * W) / O, x1 = ((ox + 1) * W + O - 1) / O;
+    uint8_t m = 0;
+    for (int yy = y0; yy < y1; ++yy)
+        for (int xx = x0; xx < x1; ++xx) {
+            const uint8_t v = lab[((int64_t)b * H + yy) * W + xx];
+            m = v > m ? v : m;
+        }
+    y[i] = m;
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256)
+void stitch_kernel(const TI* __restrict__ tiles, const int32_t* __restrict__ rc, int64_t total, int th, int tw,
+                   TO* __restrict__ grid, int gh, int gw) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int x = (int)(i % tw), yy = (int)((i / tw) % th);
+    const int64_t t = i / ((int64_t)tw * th);
+    const int r = rc[2 * t], c = rc[2 * t + 1];
+    const int64_t gy = (int64_t)r * th + yy, gx = (int64_t)c * tw + x;
+    if (gy < gh && gx < gw) grid[gy * gw + gx] = (TO)tiles[i];
+}
+
+template <int CIN, int COUT>
+int launch_direct(const void* x, int x_kind, const Norm3& nrm, const float* w, const float* bias, int B, int H, int W,
+                  float* y, int y_nchw, hipStream_t stream) {
+    const int64_t npix = (int64_t)B * H * W;
+    conv3x3_direct_kernel<CIN, COUT><<<(unsigned)vqae::ceil_div(npix, 256), 256, 0, stream>>>(
+        x, x_kind, nrm, w, bias, B, H, W, y, y_nchw);
+    VQAE_LAUNCH_CHECK();
+    return VQAE_OK;
+}
+
+template <typename TI>
+int stitch_out(const TI* tiles, const int32_t* rc, int64_t total, int th, int tw, void* grid, int gdt, int gh, int gw,
+               hipStream_t stream) {
+    const unsigned g = (unsigned)vqae::ceil_div(total, 256);
+    switch (gdt) {
+        case VQAE_IDX_I64: stitch_kernel<TI, int64_t><<<g, 256, 0, stream>>>(tiles, rc, total, th, tw, (int64_t*)grid, gh, gw); break;
+        case VQAE_IDX_U8: stitch_kernel<TI, uint8_t><<<g, 256, 0, stream>>>(tiles, rc, total, th, tw, (uint8_t*)grid, gh, gw); break;
+        case VQAE_IDX_U16: stitch_kernel<TI, uint16_t><<<g, 256, 0, stream>>>(tiles, rc, total, th, tw, (uint16_t*)grid, gh, gw); break;
+        case VQAE_IDX_I32: stitch_kernel<TI, int32_t><<<g, 256, 0, stream>>>(tiles, rc, total, th, tw, (int32_t*)grid, gh, gw); break;
+        default: return vqae::fail(VQAE_ERR_INVALID, "stitch: bad grid dtype %d", gdt);
+    }
+    VQAE_LAUNCH_CHECK();
+    return VQAE_OK;
+}
+
+}  // namespace
+
+namespace vqae {
+// internal entry shared with handle.hip: x_kind 0 NHWC f32 / 1 NCHW f32 / 2 u8 NHWC; y_nchw 0/1
+int conv3x3_direct(const void* x, int x_kind, const float* mean255, const float* inv_std255, const float* w,
+                   const float* bias, int B, int H, int W, int cin, int cout, float* y, int y_nchw,
+                   hipStream_t stream) {
+    Norm3 nrm;
+    for (int i = 0; i < 4; ++i) {
+        nrm.mean[i] = (mean255 && i < 3) ? mean255[i] : 0.f;
+        nrm.inv[i] = (inv_std255 && i < 3) ? inv_std255[i] : 1.f;
+    }
+    VQAE_REQUIRE(x && w && bias && y, VQAE_ERR_INVALID, "conv3x3_direct: null pointer");
+    VQAE_REQUIRE(x_kind != 2 || cin == 3, VQAE_ERR_UNSUPPORTED, "conv3x3_direct: uint8 input needs cin == 3");
+    if ((int64_t)B * H * W == 0) return VQAE_OK;
+#define VQAE_DIRECT_CASE(CI, CO) \
+    if (cin == CI && cout == CO) return launch_direct<CI, CO>(x, x_kind, nrm, w, bias, B, H, W, y, y_nchw, stream);
+    VQAE_DIRECT_CASE(3, 4) VQAE_DIRECT_CASE(3, 8) VQAE_DIRECT_CASE(3, 16) VQAE_DIRECT_CASE(3, 32) VQAE_DIRECT_CASE(3, 64)
+    VQAE_DIRECT_CASE(4, 3) VQAE_DIRECT_CASE(8, 3) VQAE_DIRECT_CASE(16, 3) VQAE_DIRECT_CASE(32, 3) VQAE_DIRECT_CASE(64, 3)
+#undef VQAE_DIRECT_CASE
+    return fail(VQAE_ERR_UNSUPPORTED, "conv3x3_direct: unsupported channel pair %d -> %d", cin, cout);
+}
+}  // namespace vqae
+
+extern "C" int vqae_conv3x3_direct_f32(const float* x, const uint8_t* x_u8, const float* mean255, const float* inv_std255,
+                                       const float* w, const float* bias, int B, int H, int W, int cin, int cout,
+                                       float* y, void* stream) {
+    if (x_u8)
+        return vqae::conv3x3_direct(x_u8, 2, mean255, inv_std255, w, bias, B, H, W, cin, cout, y, 0, (hipStream_t)stream);
+    return vqae::conv3x3_direct(x, 0, nullptr, nullptr, w, bias, B, H, W, cin, cout, y, 0, (hipStream_t)stream);
+}
+
+extern "C" int vqae_bicubic_up2_f32(const float* x, int B, int H, int W, int C, float pre_bias, float* y, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VQAE_REQUIRE(x && y, VQAE_ERR_INVALID, "bicubic_up2: null pointer");
+    VQAE_REQUIRE(C % 4 == 0, VQAE_ERR_UNSUPPORTED, "bicubic_up2: channels %d must be a multiple of 4", C);
+    const int64_t total = (int64_t)B * 4 * H * W * (C / 4);
+    if (total == 0) return VQAE_OK;
+    const unsigned grid = (unsigned)std::min<int64_t>(vqae::ceil_div(total, 256), 256 * 64);
+    bicubic_up2_kernel<<<grid, 256, 0, stream>>>((const float4*)x, B, H, W, C / 4, pre_bias, (float4*)y);
+    VQAE_LAUNCH_CHECK();
+    return VQAE_OK;
+}
+
+static int transpose_batched(const float* x, int B, int R, int S, float* y, hipStream_t stream) {
+    if ((int64_t)B * R * S == 0) return VQAE_OK;
+    VQAE_REQUIRE(B <= 65535, VQAE_ERR_UNSUPPORTED, "transpose: batch %d > 65535", B);
+    dim3 grid((unsigned)vqae::ceil_div(S, 32), (unsigned)vqae::ceil_div(R, 32), (unsigned)B);
+    transpose_kernel<<<grid, 256, 0, stream>>>(x, R, S, y);
+    VQAE_LAUNCH_CHECK();
+    return VQAE_OK;
+}
+
+extern "C" int vqae_nchw_to_nhwc_f32(const float* x, int B, int C, int H, int W, float* y, void* stream) {
+    VQAE_REQUIRE(x && y, VQAE_ERR_INVALID, "nchw_to_nhwc: null pointer");
+    return transpose_batched(x, B, C, H * W, y, (hipStream_t)stream);
+}
+
+extern "C" int vqae_nhwc_to_nchw_f32(const float* x, int B, int C, int H, int W, float* y, void* stream) {
+    VQAE_REQUIRE(x && y, VQAE_ERR_INVALID, "nhwc_to_nchw: null pointer");
+    return transpose_batched(x, B, H * W, C, y, (hipStream_t)stream);
+}
+
+extern "C" int vqae_label_maxpool_u8(const uint8_t* lab, int B, int H, int W, int O, uint8_t* y, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VQAE_REQUIRE(lab && y, VQAE_ERR_INVALID, "label_maxpool: null pointer");
+    VQAE_REQUIRE(O >= 1 && O <= H && O <= W, VQAE_ERR_INVALID, "label_maxpool: output %d larger than input", O);
+    const int64_t total = (int64_t)B * O * O;
+    if (total == 0) return VQAE_OK;
+    label_maxpool_kernel<<<(unsigned)vqae::ceil_div(total, 256), 256, 0, stream>>>(lab, B, H, W, O, y);
+    VQAE_LAUNCH_CHECK();
+    return VQAE_OK;
+}
+
+extern "C" int vqae_stitch_tiles(const void* tiles, int idx_dtype, const int32_t* rc, int n_tiles, int th, int tw,
+                                 void* grid, int grid_dtype, int gh, int gw, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VQAE_REQUIRE(tiles && rc && grid, VQAE_ERR_INVALID, "stitch: null pointer");
+    const int64_t total = (int64_t)n_tiles * th * tw;
+    if (total == 0) return VQAE_OK;
+    switch (idx_dtype) {
+        case VQAE_IDX_I64: return stitch_out((const int64_t*)tiles, rc, total, th, tw, grid, grid_dtype, gh, gw, stream);
+        case VQAE_IDX_U8: return stitch_out((const uint8_t*)tiles, rc, total, th, tw, grid, grid_dtype, gh, gw, stream);
+        case VQAE_IDX_U16: return stitch_out((const uint16_t*)tiles, rc, total, th, tw, grid, grid_dtype, gh, gw, stream);
+        case VQAE_IDX_I32: return stitch_out((const int32_t*)tiles, rc, total, th, tw, grid, grid_dtype, gh, gw, stream);
+        default: return vqae::fail(VQAE_ERR_INVALID, "stitch: bad tile dtype %d", idx_dtype);
+    }
+}

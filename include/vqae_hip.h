@@ -1,0 +1,215 @@
+/* vqae_hip.h -- C ABI of libvqae_hip.so: the MI355X (gfx950) native VQ-AE inference hot path.
+ *
+ * Drop-in boundary for sara-nl/2D-VQ-AE-2's conv-encoder -> vector-quantise -> conv-decoder
+ * forward pass.  The reference has no native interface: its plugin mechanism is
+ * Hydra `_target_` class-path substitution (conf/model/layers/vq/ema_vq.yaml:1,
+ * conf/model/layers/conv_block/pre_activation_fixup.yaml:24, conf/model/{encoder,decoder}/default.yaml) over
+ * nn.Module.forward contracts.  Each entry point below cites the reference interface it replaces;
+ * INTEGRATION.md shows the ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - plain C types only; every `*_dev` pointer is a device (HBM) pointer owned by the caller;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all calls are
+ *     asynchronous on it and allocate nothing (handle workspaces grow only inside
+ *     vqae_reserve / on the first call with a larger batch, never during steady state);
+ *   - activations are fp32, NHWC ("channels-last": [B][H][W][C], C contiguous).  NCHW tensors
+ *     (the reference's layout, model.py:189) cross the boundary through vqae_nchw_to_nhwc /
+ *     vqae_nhwc_to_nchw or the `layout` argument of the handle-level calls;
+ *   - return value: 0 on success, negative vqae_status otherwise; vqae_last_error() returns a
+ *     thread-local message.  The Python binding maps them back to the reference's exception
+ *     types (AssertionError / NotImplementedError / ValueError), see vqae_status.
+ */
+#ifndef VQAE_HIP_H
+#define VQAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum vqae_status {
+    VQAE_OK = 0,
+    VQAE_ERR_INVALID = -1,        /* bad argument / failed assert  (reference: AssertionError, vq.py:98, conv_block.py:148) */
+    VQAE_ERR_UNSUPPORTED = -2,    /* reference: NotImplementedError (vq.py:100-104) */
+    VQAE_ERR_HIP = -3,            /* HIP runtime failure */
+    VQAE_ERR_NOMEM = -4,
+    VQAE_ERR_NOT_FOUND = -5       /* missing tensor name in a weight set (reference: KeyError in load_state_dict) */
+} vqae_status;
+
+enum { VQAE_LAYOUT_NHWC = 0, VQAE_LAYOUT_NCHW = 1 };
+enum { VQAE_IDX_I64 = 0, VQAE_IDX_U8 = 1, VQAE_IDX_U16 = 2, VQAE_IDX_I32 = 3 };
+
+const char* vqae_last_error(void);
+/* "gfx950;<git describe or build date>" */
+const char* vqae_build_info(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * 1. Vector quantiser  -- replaces EMAVectorQuantizer.forward, vq_ae/layers/vq.py:96-154
+ *    (eval mode) and embed_code, vq.py:44-45.
+ * ------------------------------------------------------------------------------------------- */
+
+/* Bytes of scratch vqae_vq_forward_f32 needs for N rows (tie re-check list, loss partials). */
+size_t vqae_vq_workspace_bytes(int64_t n_rows, int n_codes, int dim);
+
+/* idx[n] = argmin_k ( sum_c |z[n][c] - embed[k][c]|^4 )^(1/4), lowest k on ties
+ *          (vq.py:121-129: torch.cdist(flat, embed, p = inputs.dim() = 4) + argmin(dim=1));
+ * q[n]   = z[n] + (embed[idx[n]] - z[n])        (vq.py:130,146: lookup + straight-through value);
+ * *loss  = commitment_cost * mean((z - embed[idx])^2)   (vq.py:143).
+ *   z_dev     [n_rows][dim] fp32 (the NHWC activation, i.e. the reference's `flat_input`, vq.py:116)
+ *   embed_dev [n_codes][dim] fp32 (buffer `embed`, vq.py:27)
+ *   idx_dev   [n_rows] of idx_dtype (VQAE_IDX_*); required
+ *   q_dev     [n_rows][dim] fp32 or NULL;  loss_dev  one fp32 or NULL
+ *   margin_dev [n_rows] fp32 or NULL: relative gap between best and second-best 4th-power sums
+ *   workspace_dev: vqae_vq_workspace_bytes(...) bytes.
+ * Errors: dim not a multiple of 4, n_codes < 1 or > 65536 -> VQAE_ERR_UNSUPPORTED. */
+int vqae_vq_forward_f32(const float* z_dev, const float* embed_dev, int64_t n_rows, int n_codes, int dim,
+                        float commitment_cost, void* idx_dev, int idx_dtype, float* q_dev, float* loss_dev,
+                        float* margin_dev, void* workspace_dev, void* stream);
+
+/* out[n][:] = embed[idx[n]][:]   (embed_code, vq.py:44-45 = F.embedding) */
+int vqae_embed_code_f32(const void* idx_dev, int idx_dtype, const float* embed_dev, int64_t n_rows, int n_codes,
+                        int dim, float* out_dev, void* stream);
+
+/* Training-mode bookkeeping (vq.py:47-74 `_update_ema`): counts n_k and sums dw_k of the rows
+ * assigned to each code.  counts_dev [n_codes] fp32, dw_dev [n_codes][dim] fp32 (both overwritten). */
+int vqae_vq_code_stats_f32(const float* z_dev, const void* idx_dev, int idx_dtype, int64_t n_rows, int n_codes,
+                           int dim, float* counts_dev, float* dw_dev, void* stream);
+/* EMA + Laplace smoothing step of `_update_ema` (vq.py:60-74), after the caller all-reduced
+ * counts/dw over ranks (vq.py:57-58): updates cluster_size, embed_avg, embed in place. */
+int vqae_vq_ema_update_f32(float* embed_dev, float* embed_avg_dev, float* cluster_size_dev, const float* counts_dev,
+                           const float* dw_dev, int n_codes, int dim, float decay, float laplace_alpha,
+                           void* workspace_dev /* >= 16 bytes */, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * 2. Conv stack primitives -- replace the torch.nn.Conv2d / ELU / Upsample call sites of
+ *    PreActFixupResBlock.forward (vq_ae/layers/conv_block.py:196-216) and ResizeConv2D.forward
+ *    (vq_ae/layers/conv.py:10-11).
+ * ------------------------------------------------------------------------------------------- */
+
+enum { VQAE_PAD_NONE = 0, VQAE_PAD_CIRCULAR = 1, VQAE_PAD_ZEROS = 2 };
+enum { VQAE_PRE_NONE = 0, VQAE_PRE_BIAS = 1, VQAE_PRE_BIAS_ELU_BIAS = 2 };
+
+/* Floats needed for the packed form of a [cout][cin][k][k] weight (rows padded to 32 couts). */
+size_t vqae_conv_packed_floats(int cout, int cin, int ksize);
+/* Repack a PyTorch-layout conv weight [cout][cin][k][k] (device) into the kernel's
+ * [cout_pad][k*k*cin] layout (tap-major K, zero rows for the pad). */
+int vqae_conv_pack_weight_f32(const float* w_oihw_dev, int cout, int cin, int ksize, float* packed_dev,
+                              void* stream);
+
+typedef struct vqae_conv_args {
+    /* geometry: y[b][oy][ox][:] = sum_{dy,dx,ci} W[:, ci, dy, dx] * pre(x[b][oy*stride+dy-pad][ox*stride+dx-pad][ci]) */
+    int batch, in_h, in_w, cin, cout;
+    int ksize;            /* 1, 2 or 3 */
+    int stride;           /* 1 or 2 */
+    int pad;              /* 0 or 1 */
+    int pad_mode;         /* VQAE_PAD_* (circular: padding_mode='circular', pre_activation_fixup.yaml:56-58) */
+    /* pre-op on the input (Fixup scalar biases, conv_block.py:199-206,211):
+     *   VQAE_PRE_BIAS:           x + pre_a
+     *   VQAE_PRE_BIAS_ELU_BIAS:  ELU(x + pre_a) + pre_b        (ELU alpha = 1, activation/elu.yaml) */
+    int pre_mode;
+    float pre_a, pre_b;
+    /* epilogue, in the reference's rounding order (conv_block.py:208-214):
+     *   t = acc; if (has_scale) t = t * scale + bias_s;  else if (has_bias_s) t = t + bias_s;
+     *   if (bias_vec) t = t + bias_vec[c];   if (residual) t = t + residual[m][c];
+     *   if (has_act) t = ELU(t + act_a) + act_b;   (the NEXT conv's pre-op, fused here) */
+    int has_scale, has_bias_s, has_act;
+    float scale, bias_s, act_a, act_b;
+} vqae_conv_args;
+
+/* x_dev [B][H][W][cin], w_packed_dev from vqae_conv_pack_weight_f32, bias_vec_dev [cout] or NULL,
+ * residual_dev [B][Ho][Wo][cout] or NULL, y_dev [B][Ho][Wo][cout].  fp32 MFMA implicit GEMM.
+ * Requires cin % 8 == 0 (use vqae_conv_small_cin_f32 for the 3-channel stem). */
+int vqae_conv2d_f32(const vqae_conv_args* a, const float* x_dev, const float* w_packed_dev,
+                    const float* bias_vec_dev, const float* residual_dev, float* y_dev, void* stream);
+
+/* Direct (VALU) 3x3 / stride 1 / zero-pad conv with per-channel bias for tiny channel counts:
+ * the stems `in_stem` (3 -> C0, model.py:198) and `out_stem` (C0 -> 3, model.py:291).
+ * w_oihw_dev is the PyTorch-layout weight [cout][cin][3][3]; cin, cout <= 64.
+ * If x_u8_dev != NULL the input is uint8 NHWC and is normalised on the fly
+ * ((u - mean255[c]) * inv_std255[c], albumentations Normalize, camelyon16_transforms.yaml:15-23). */
+int vqae_conv3x3_direct_f32(const float* x_dev, const uint8_t* x_u8_dev, const float* mean255, const float* inv_std255,
+                            const float* w_oihw_dev, const float* bias_dev, int batch, int h, int w, int cin,
+                            int cout, float* y_dev, void* stream);
+
+/* y = bicubic_x2(x + pre_bias), A = -0.75, align_corners = False, index-clamped borders
+ * (nn.Upsample(mode='bicubic', scale_factor=2), layers/conv.py:8).  x [B][H][W][C] -> y [B][2H][2W][C]. */
+int vqae_bicubic_up2_f32(const float* x_dev, int batch, int h, int w, int c, float pre_bias, float* y_dev,
+                         void* stream);
+
+/* Layout shuffles at the boundary (reference tensors are NCHW, model.py:189). */
+int vqae_nchw_to_nhwc_f32(const float* x_dev, int batch, int c, int h, int w, float* y_dev, void* stream);
+int vqae_nhwc_to_nchw_f32(const float* x_dev, int batch, int c, int h, int w, float* y_dev, void* stream);
+
+/* labels [B][H][W] (u8) -> [B][out][out] max over (H/out x W/out) windows
+ * (F.adaptive_max_pool2d in run_eval, scripts/extract_embeddings/extract_embeddings.py:127-130). */
+int vqae_label_maxpool_u8(const uint8_t* labels_dev, int batch, int h, int w, int out, uint8_t* y_dev, void* stream);
+
+/* Stitch code tiles into a slide grid (get_encodings, extract_embeddings.py:77-84):
+ * grid[(r*th + y) * grid_w + c*tw + x] = tiles[t][y][x] for tile t at patch position (r, c) = rc[t].
+ * tiles idx_dtype in, grid_dtype out (VQAE_IDX_*; narrowing is the caller's cast_to_lowest_dtype choice). */
+int vqae_stitch_tiles(const void* tiles_dev, int idx_dtype, const int32_t* rc_dev, int n_tiles, int th, int tw,
+                      void* grid_dev, int grid_dtype, int grid_h, int grid_w, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * 3. Whole-model handle -- replaces Encoder.forward (vq_ae/model.py:189-217), Decoder.forward
+ *    (:274-291) and VQAE.forward (:41-48) for the single-VQ-level Fixup model that every shipped
+ *    config composes.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct vqae_config {
+    int in_channels;      /* 3                 conf/model/vq_ae.yaml:23 */
+    int stem;             /* stem out_channels vq_ae.yaml:24 */
+    int n_down;           /* vq_ae.yaml:26 */
+    int n_pre, n_post;    /* vq_ae.yaml:27-28 */
+    int n_enc;            /* n_pre_enc_layers = n_post_enc_layers, vq_ae.yaml:29,39 */
+    int num_embeddings;   /* layers/vq/ema_vq.yaml:2 */
+    int projection_dim;   /* 0: EMAVectorQuantizer; >0: ProjectedEMAVectorQuantizer2d (vq.py:157-192) */
+    float commitment_cost;
+} vqae_config;
+
+/* One named fp32 host tensor, named as in the reference's state_dict, e.g.
+ * "encoder.pre_enc_layers.0.7.branch_conv2.weight" with PyTorch shapes ([cout][cin][k][k], (1,) ...). */
+typedef struct vqae_tensor {
+    const char* name;
+    const float* data;    /* host pointer */
+    int64_t numel;
+} vqae_tensor;
+
+typedef struct vqae_handle vqae_handle;
+
+int vqae_create(const vqae_config* cfg, const vqae_tensor* tensors, int n_tensors, vqae_handle** out);
+void vqae_destroy(vqae_handle* h);
+/* Pre-size the internal workspace for `max_batch` patches of in_h x in_w (optional). */
+int vqae_reserve(vqae_handle* h, int max_batch, int in_h, int in_w);
+/* Replace the codebook (e.g. after calibration / EMA updates): embed_host [K][D] fp32. */
+int vqae_set_codebook(vqae_handle* h, const float* embed_host);
+
+/* Encoder.forward: x [B,3,H,W] (layout per `layout`) -> idx [B][h][w] (idx_dtype), optional
+ * q_dev [B][C][h][w] (fp32, `layout`), optional loss_dev (one fp32).  h = H / 2^n_down. */
+int vqae_encode(vqae_handle* h, const float* x_dev, int batch, int in_h, int in_w, int layout, void* idx_dev,
+                int idx_dtype, float* q_dev, float* loss_dev, void* stream);
+/* Same, from raw uint8 NHWC patches normalised on device. */
+int vqae_encode_u8(vqae_handle* h, const uint8_t* x_u8_dev, int batch, int in_h, int in_w, void* idx_dev,
+                   int idx_dtype, float* q_dev, int q_layout, float* loss_dev, void* stream);
+/* Pre-VQ activations z [B][h][w][C] NHWC (for codebook calibration, vq.py:76-94 `_init_ema`);
+ * with projection, the projected [B][h][w][D] tensor. */
+int vqae_encode_features(vqae_handle* h, const float* x_dev, int batch, int in_h, int in_w, int layout,
+                         float* z_dev, void* stream);
+/* Decoder.forward: q [B][C][h][w] -> out [B,3,H,W]  (q_h, q_w = latent grid size). */
+int vqae_decode(vqae_handle* h, const float* q_dev, int batch, int q_h, int q_w, int layout, float* out_dev,
+                void* stream);
+/* Decode from code indices: embed_code (+ proj_out) then Decoder.forward. */
+int vqae_decode_indices(vqae_handle* h, const void* idx_dev, int idx_dtype, int batch, int q_h, int q_w, int layout,
+                        float* out_dev, void* stream);
+/* VQAE.forward: out [B,3,H,W], idx (optional), loss (optional). */
+int vqae_forward(vqae_handle* h, const float* x_dev, int batch, int in_h, int in_w, int layout, float* out_dev,
+                 void* idx_dev, int idx_dtype, float* loss_dev, void* stream);
+
+/* Introspection for benchmarks: algorithmic FLOPs (2*MACs) of the conv stacks per patch. */
+double vqae_flops_per_patch(const vqae_handle* h, int in_h, int in_w, int encoder, int decoder);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VQAE_HIP_H */

@@ -1,0 +1,81 @@
+"""CPU: libvqae_hip.so loads, exports every symbol include/vqae_hip.h declares, and its argument
+validation (which runs before any HIP call) reports errors through the documented convention.
+No compute is launched here (there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "vqae_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vqae_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_all_exported(amd):
+    lib = amd._lib.lib()
+    names = declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/vqae_hip.h but not exported"
+    assert set(names) == set(amd._lib.SYMBOLS), set(names) ^ set(amd._lib.SYMBOLS)
+
+
+def test_build_info_and_sizes(amd):
+    lib = amd._lib.lib()
+    assert lib.vqae_build_info().startswith(b"gfx950")
+    assert lib.vqae_conv_packed_floats(128, 128, 3) == 128 * 9 * 128
+    assert lib.vqae_conv_packed_floats(16, 16, 1) == 128 * 16          # rows padded to 128
+    assert lib.vqae_vq_workspace_bytes(1024, 256, 128) >= 256 * 128 * 4 + 2 * 1024 * 4
+
+
+def test_error_convention_without_gpu(amd):
+    L = amd._lib
+    lib = L.lib()
+    # null pointers -> VQAE_ERR_INVALID -> AssertionError (reference: assert, vq.py:98)
+    with pytest.raises(AssertionError):
+        L.check(lib.vqae_vq_forward_f32(None, None, 16, 4, 8, 1.0, None, 0, None, None, None, None, None))
+    a = L.ConvArgs()
+    a.batch, a.in_h, a.in_w, a.cin, a.cout, a.ksize, a.stride = 1, 8, 8, 3, 8, 3, 1
+    one = ctypes.c_void_p(16)          # never dereferenced: validation fails first
+    with pytest.raises(NotImplementedError):      # cin % 8 != 0 -> VQAE_ERR_UNSUPPORTED
+        L.check(lib.vqae_conv2d_f32(ctypes.byref(a), one, one, None, None, one, None))
+    assert b"cin" in lib.vqae_last_error()
+    with pytest.raises(NotImplementedError):      # dim % 4 != 0
+        L.check(lib.vqae_vq_forward_f32(one, one, 16, 4, 6, 1.0, one, 0, None, None, None, one, None))
+
+
+def test_ops_refuse_cpu_tensors(amd):
+    import torch
+    with pytest.raises(amd._lib.VqaeHipError):
+        amd.ops.vq_forward(torch.zeros(4, 8), torch.zeros(2, 8))
+
+
+def test_state_dict_names_match_reference(amd, oracle):
+    """The module mirrors expose exactly the reference's state-dict names/shapes."""
+    from vqae_amd.model import VQAE
+    for name in ("tiny", "tinyP"):
+        m = VQAE.from_spec(amd.SPECS[name])
+        sd = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        ref = oracle.param_shapes(oracle.SPECS[name])
+        for k, shp in ref.items():
+            assert sd[k] == tuple(shp), k
+        extra = set(sd) - set(ref)
+        assert all(k.endswith(("embed_avg", "cluster_size", "first_pass")) for k in extra), extra
+
+
+def test_reference_error_types(amd):
+    from vqae_amd.layers.conv_block import PreActFixupResBlock
+    from vqae_amd.layers.vq import EMAVectorQuantizer
+    import torch
+    with pytest.raises(AssertionError):               # conv_block.py:148
+        PreActFixupResBlock(8, 8, "sideways")
+    vq = EMAVectorQuantizer(16, 8, 1.0, 0.99, 1e-5)
+    with pytest.raises(AssertionError):               # vq.py:98
+        vq(torch.zeros(4, 8))
+    with pytest.raises(NotImplementedError):          # vq.py:100-104
+        vq(torch.zeros(1, 4, 2, 2))

@@ -1,0 +1,152 @@
+"""GPU parity: conv-stack primitives (through the C ABI) against plain PyTorch fp32 on the CPU.
+Tolerance: fp32 implicit GEMM vs oneDNN differ only in summation order -> |err| <= 2e-5 * scale."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def close(a, b, tol=2e-5):
+    scale = max(1.0, float(b.abs().max()))
+    err = float((a - b).abs().max())
+    assert err <= tol * scale, f"max err {err:.3e} vs scale {scale:.3e}"
+
+
+GEOMS = [  # (ksize, stride, pad, circular)
+    (1, 1, 0, False), (3, 1, 1, True), (2, 2, 0, False), (3, 1, 1, False),
+]
+
+
+@pytest.mark.parametrize("ks,stride,pad,circ", GEOMS)
+@pytest.mark.parametrize("cin,cout,hw,b", [(128, 128, 32, 3), (16, 16, 40, 2), (8, 16, 24, 2), (32, 64, 16, 5),
+                                           (64, 32, 8, 3), (256, 256, 16, 1), (24, 40, 12, 2), (128, 8, 32, 1)])
+def test_conv_geometries(amd, ks, stride, pad, circ, cin, cout, hw, b):
+    L = amd._lib
+    g = torch.Generator().manual_seed(cin * 31 + cout + ks)
+    x = torch.randn(b, cin, hw, hw, generator=g)
+    w = torch.randn(cout, cin, ks, ks, generator=g) / (cin * ks * ks) ** 0.5
+    if circ:
+        xp = F.pad(x, (1, 1, 1, 1), mode="circular")
+        ref = F.conv2d(xp, w, stride=stride)
+    else:
+        ref = F.conv2d(x, w, stride=stride, padding=pad)
+    wp = amd.ops.pack_conv_weight(w.cuda())
+    y = amd.ops.conv2d(nhwc(x).cuda(), wp, cout, ks, stride, pad,
+                       L.PAD_CIRCULAR if circ else (L.PAD_ZEROS if pad else L.PAD_NONE))
+    torch.cuda.synchronize()
+    close(nchw(y.cpu()), ref)
+
+
+def test_conv_fixup_pre_and_epilogue(amd):
+    """The fused Fixup ops: ELU(x+a)+b pre-op, *scale+bias+residual and ELU epilogues
+    (conv_block.py:199-214), in the reference's rounding order."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 32, 16, 16, generator=g)
+    w = torch.randn(32, 32, 1, 1, generator=g) / 32 ** 0.5
+    res = torch.randn(2, 32, 16, 16, generator=g)
+    bv = torch.randn(32, generator=g)
+    wp = amd.ops.pack_conv_weight(w.cuda())
+    xc, rc = nhwc(x).cuda(), nhwc(res).cuda()
+    # conv1-style
+    ref = F.elu(F.conv2d(F.elu(x + 0.3) + (-0.2), w) + 0.11) + 0.07
+    y = amd.ops.conv2d(xc, wp, 32, 1, pre=(0.3, -0.2), act=(0.11, 0.07))
+    close(nchw(y.cpu()), ref)
+    # conv3-style, in place over the residual
+    ref = F.conv2d(x, w) * 1.3 + 0.05 + res
+    y = amd.ops.conv2d(xc, wp, 32, 1, scale_bias=(1.3, 0.05), residual=rc, out=rc)
+    close(nchw(y.cpu()), ref)
+    # skip-style: conv(x + c) + d ; projection-style: per-channel bias
+    ref = F.conv2d(x + 0.4, w) + 0.25
+    close(nchw(amd.ops.conv2d(xc, wp, 32, 1, pre=(0.4,), bias_s=0.25).cpu()), ref)
+    ref = F.conv2d(x, w, bv)
+    close(nchw(amd.ops.conv2d(xc, wp, 32, 1, bias_vec=bv.cuda()).cpu()), ref)
+
+
+def test_conv_ragged_m_and_empty(amd):
+    g = torch.Generator().manual_seed(4)
+    w = torch.randn(16, 8, 3, 3, generator=g) / 72 ** 0.5
+    wp = amd.ops.pack_conv_weight(w.cuda())
+    for b, hw in [(1, 5), (3, 7), (1, 11)]:                      # M = 25, 147, 121: not multiples of 128
+        x = torch.randn(b, 8, hw, hw, generator=g)
+        ref = F.conv2d(F.pad(x, (1, 1, 1, 1), mode="circular"), w)
+        y = amd.ops.conv2d(nhwc(x).cuda(), wp, 16, 3, 1, 1, amd._lib.PAD_CIRCULAR)
+        close(nchw(y.cpu()), ref)
+    y = amd.ops.conv2d(torch.zeros(0, 4, 4, 8).cuda(), wp, 16, 3, 1, 1, amd._lib.PAD_CIRCULAR)
+    assert y.shape == (0, 4, 4, 16)
+
+
+def test_mfma_operand_layout_asymmetric(amd):
+    """A = identity-like input with an asymmetric weight catches swapped C/D row<->col maps."""
+    cin = cout = 64
+    x = torch.zeros(1, cin, 8, 16)
+    for c in range(cin):
+        x[0, c, c % 8, (c * 3) % 16] = 1.0 + c
+    w = (torch.arange(cout * cin, dtype=torch.float32).reshape(cout, cin, 1, 1) % 97) / 97.0
+    ref = F.conv2d(x, w)
+    y = amd.ops.conv2d(nhwc(x).cuda(), amd.ops.pack_conv_weight(w.cuda()), cout, 1)
+    close(nchw(y.cpu()), ref, 1e-6)
+
+
+@pytest.mark.parametrize("cin,cout", [(3, 8), (3, 16), (3, 32), (8, 3), (16, 3), (32, 3)])
+def test_stem_conv_direct(amd, cin, cout):
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(2, cin, 20, 28, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+    b = torch.randn(cout, generator=g)
+    y = amd.ops.conv3x3_direct(nhwc(x).cuda(), w.cuda(), b.cuda())
+    close(nchw(y.cpu()), F.conv2d(x, w, b, padding=1))
+
+
+def test_stem_conv_uint8_ingest(amd, oracle):
+    u8 = oracle.make_patches_u8(2, 32, 3)
+    x = oracle.normalize_u8(u8)
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(16, 3, 3, 3, generator=g) / 27 ** 0.5
+    b = torch.randn(16, generator=g)
+    mean = [m * 255 for m in oracle.MEAN]
+    inv = [1.0 / (s * 255) for s in oracle.STD]
+    y = amd.ops.conv3x3_direct(None, w.cuda(), b.cuda(), x_u8=torch.from_numpy(u8).cuda(), mean255=mean,
+                               inv_std255=inv)
+    close(nchw(y.cpu()), F.conv2d(x, w, b, padding=1))
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 9, 7), (1, 32, 16, 16), (3, 4, 1, 5)])
+def test_bicubic_up2(amd, oracle, shape):
+    x = torch.randn(*shape)
+    y = nchw(amd.ops.bicubic_up2(nhwc(x).cuda(), 0.125).cpu())
+    ref = oracle.bicubic_up2_explicit(x + 0.125)
+    assert torch.equal(y, ref), float((y - ref).abs().max())         # same taps, same order: bit-exact
+    close(y, oracle.bicubic_up2(x + 0.125), 1e-6)                     # ATen's own kernel: <= 1 ulp-ish
+
+
+def test_layout_roundtrip_and_helpers(amd, oracle):
+    x = torch.randn(3, 20, 6, 10)
+    y = amd.ops.nchw_to_nhwc(x.cuda())
+    assert torch.equal(y.cpu(), nhwc(x))
+    assert torch.equal(amd.ops.nhwc_to_nchw(y).cpu(), x)
+    lab = (torch.rand(3, 64, 64) > 0.97).to(torch.uint8)
+    pooled = amd.ops.label_maxpool(lab.cuda(), 32).cpu().numpy()
+    assert np.array_equal(pooled, oracle.adaptive_max_pool_labels(lab.numpy(), 32))
+
+
+def test_stitch_tiles_matches_driver_fixture(amd, oracle):
+    from conftest import load_golden
+    g = load_golden("driver")
+    tiles, meta, sizes = g["tiles"], g["meta"], g["sizes"]
+    for s, name in enumerate(["images/slide_a", "images/slide_b"]):
+        sel = meta[:, 0] == s
+        r, c = sizes[s]
+        grid = torch.full((int(r) * 4, int(c) * 4), -1, dtype=torch.int64).cuda()
+        amd.ops.stitch_tiles(torch.from_numpy(tiles[sel]).cuda(), torch.from_numpy(meta[sel][:, 1:]).cuda(), grid)
+        out = oracle.cast_to_lowest_dtype(grid.cpu().numpy())
+        assert out.dtype == g["grid:" + name].dtype and np.array_equal(out, g["grid:" + name])

@@ -1,0 +1,111 @@
+"""CPU: the oracle restatement replays the golden fixtures that tests/golden/make_golden.py
+recorded from the imported reference (no GPU, no reference needed at test time)."""
+import ast
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+
+@pytest.mark.parametrize("D,K", [(8, 256), (128, 256), (256, 1024), (32, 16)])
+def test_vq_oracle_matches_reference_fixture(oracle, D, K):
+    g = load_golden(f"vq_D{D}_K{K}")
+    N = int(g["N"])
+    z, embed = oracle.make_vq_case(D, K, N, seed=int(g["seed"]))
+    hw = 32 if N % 1024 == 0 else 16
+    zin = z.reshape(N // (hw * hw), hw, hw, D).permute(0, 3, 1, 2).contiguous()
+    q, idx, loss = oracle.vq_forward(zin, embed, 1.0)
+    assert np.array_equal(idx.reshape(-1).numpy(), g["idx"].astype(np.int64))      # bit-exact indices
+    assert float(loss) == float(g["loss"])
+    assert np.array_equal(q.permute(0, 2, 3, 1).reshape(N, D)[::61].numpy(), g["q_flat_sample"])
+    assert float(g["cdist_bitwise_match"]) == 1.0          # C restatement == torch.cdist, every entry
+
+
+def test_vq_tie_rule_lowest_index(oracle):
+    z, embed = oracle.make_vq_case(32, 16, 1024, seed=0)
+    idx, best, second = oracle.vq_argmin_p4(z, embed)
+    # rows 0..3 are exact copies of codes duplicated at K-1-i and i: the lower index must win
+    assert idx[:4].tolist() == [0, 1, 2, 3]
+    assert torch.all(best[:4] == 0) and torch.all(second[:4] == 0)
+
+
+def test_vq_numpy_crosscheck(oracle):
+    z, embed = oracle.make_vq_case(8, 256, 512, seed=1)
+    idx, _, _ = oracle.vq_argmin_p4(z, embed)
+    assert np.array_equal(oracle.vq_argmin_p4_numpy(z.numpy(), embed.numpy()), idx.numpy())
+
+
+@pytest.mark.parametrize("name", ["tiny", "tinyP"])
+def test_model_taps_match_reference_fixture(oracle, name):
+    g = load_golden(f"model_{name}")
+    spec = oracle.SPECS[name]
+    assert ast.literal_eval(str(g["spec"])) == spec.to_dict()
+    p = oracle.make_params(spec, 0)
+    p["encoder.vq_layers.0.embed"] = torch.from_numpy(g["embed"])
+    x = torch.from_numpy(g["x"])
+    assert torch.equal(x, oracle.make_patches(int(g["batch"]), int(g["size"]), 0))
+    taps = {}
+    out, losses = oracle.vqae_forward(x, p, spec, taps)
+    assert np.array_equal(taps["idx"].numpy(), g["idx"].astype(np.int64))
+    assert float(losses[0]) == float(g["loss"])
+    for k in g.files:
+        if k.startswith("tap:") and k[4:] in taps:
+            assert np.array_equal(taps[k[4:]].numpy(), g[k]), k
+    assert np.array_equal(out.numpy(), g["tap:out"])
+
+
+def test_model_B_matches_reference_fixture(oracle):
+    """BASELINE config #1 (cfg B, batch 4, fp32, CPU): the oracle reproduces the reference's indices,
+    loss and output samples exactly."""
+    g = load_golden("model_B")
+    spec = oracle.SPECS["B"]
+    p = oracle.make_params(spec, 0)
+    p["encoder.vq_layers.0.embed"] = torch.from_numpy(g["embed"])
+    x = oracle.make_patches(int(g["batch"]), int(g["size"]), 0)
+    taps = {}
+    out, losses = oracle.vqae_forward(x, p, spec, taps)
+    assert np.array_equal(taps["idx"].numpy(), g["idx"].astype(np.int64))
+    assert float(losses[0]) == float(g["loss"])
+    assert np.array_equal(out[:, :, ::16, ::16].numpy(), g["out_sample"])
+    assert abs(float(((out - x) ** 2).mean()) - float(g["recon_mse"])) < 1e-6 * float(g["recon_mse"])
+
+
+def test_bicubic_explicit_restatement(oracle):
+    x = torch.randn(2, 8, 9, 7)
+    a, b = oracle.bicubic_up2(x), oracle.bicubic_up2_explicit(x)
+    assert (a - b).abs().max() <= 4 * torch.finfo(torch.float32).eps * x.abs().max()
+
+
+def test_driver_fixture(oracle):
+    g = load_golden("driver")
+    tiles, meta, sizes = g["tiles"], g["meta"], g["sizes"]
+    for s, name in enumerate(["images/slide_a", "images/slide_b"]):
+        sel = tiles[meta[:, 0] == s]
+        grid = oracle.cast_to_lowest_dtype(oracle.stitch_slide(sel, *sizes[s]))
+        ref = g["grid:" + name]
+        assert grid.dtype == ref.dtype and np.array_equal(grid, ref)
+    assert g["grid:images/slide_b"].dtype == np.bool_
+    assert g["grid:images/slide_a"].dtype == np.uint8
+
+
+def test_ema_fixture(oracle):
+    g = load_golden("ema")
+    D, K = int(g["D"]), int(g["K"])
+    z0, embed = oracle.make_vq_case(D, K, 1024, seed=3, adversarial=False)
+    z1, _ = oracle.make_vq_case(D, K, 1024, seed=4, adversarial=False)
+    e, ea, cs = oracle.init_ema(z0 * 1.7 + 0.3, embed, embed.clone(), torch.zeros(K))
+    for step, z in enumerate((z0 * 1.7 + 0.3, z1 * 1.7 + 0.3)):
+        idx, _, _ = oracle.vq_argmin_p4(z, e)
+        assert np.array_equal(idx.numpy(), g[f"idx{step}"].astype(np.int64))
+        e, ea, cs = oracle.update_ema(z, idx, ea, cs, 0.99, 1e-5)
+        np.testing.assert_allclose(e.numpy(), g[f"embed{step}"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(ea.numpy(), g[f"embed_avg{step}"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(cs.numpy(), g[f"cluster_size{step}"], rtol=1e-6, atol=1e-7)
+
+
+def test_label_maxpool_matches_torch(oracle):
+    lab = (torch.rand(3, 64, 64) > 0.97).to(torch.uint8)
+    ref = torch.nn.functional.adaptive_max_pool2d(lab[:, None].half().float(), 32)[:, 0].to(torch.uint8)
+    assert np.array_equal(oracle.adaptive_max_pool_labels(lab.numpy(), 32), ref.numpy())

@@ -1,0 +1,113 @@
+"""GPU parity: the HIP vector quantiser (through the C ABI) against the CPU oracle.
+Bar: code indices bit-exact on identical inputs; q bit-exact; loss within 1e-6 relative."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def run_hip(amd, z, embed, **kw):
+    q, idx, loss, margin = amd.ops.vq_forward(z.cuda(), embed.cuda(), 1.0, want_margin=True, **kw)
+    torch.cuda.synchronize()
+    return q.cpu(), idx.cpu(), float(loss), margin.cpu()
+
+
+@pytest.mark.parametrize("D,K", [(8, 256), (128, 256), (256, 1024), (32, 16)])
+def test_vq_matches_golden_and_oracle(amd, oracle, D, K):
+    g = load_golden(f"vq_D{D}_K{K}")
+    N = int(g["N"])
+    z, embed = oracle.make_vq_case(D, K, N, seed=int(g["seed"]))
+    q, idx, loss, margin = run_hip(amd, z, embed)
+    ref = g["idx"].astype(np.int64)
+    assert np.array_equal(idx.numpy(), ref), f"{(idx.numpy() != ref).sum()} index mismatches"
+    # q = z + (e[idx] - z), bitwise (vq.py:146)
+    e = embed[idx]
+    assert torch.equal(q, z + (e - z))
+    assert np.array_equal(q[::61].numpy(), g["q_flat_sample"])
+    assert abs(loss - float(g["loss"])) <= 1e-6 * abs(float(g["loss"]))
+    # adversarial rows: exact duplicates -> margin 0 -> resolved to the lowest index
+    assert idx[:4].tolist() == [0, 1, 2, 3]
+    assert torch.all(margin[:4] == 0)
+
+
+@pytest.mark.parametrize("N", [1, 7, 127, 128, 129, 1000])
+@pytest.mark.parametrize("D,K", [(8, 256), (128, 256), (64, 300), (12, 5)])
+def test_vq_ragged_sizes(amd, oracle, N, D, K):
+    z, embed = oracle.make_vq_case(D, K, max(N, 128), seed=5, adversarial=K >= 32)
+    z = z[:N].contiguous()
+    q, idx, loss, _ = run_hip(amd, z, embed)
+    oidx, _, _ = oracle.vq_argmin_p4(z, embed)
+    assert torch.equal(idx, oidx)
+    ref_loss = float(((z - embed[oidx]) ** 2).double().mean())
+    assert abs(loss - ref_loss) <= 2e-6 * max(ref_loss, 1e-30)
+
+
+def test_vq_empty(amd):
+    q, idx, loss, _ = amd.ops.vq_forward(torch.zeros(0, 8).cuda(), torch.randn(4, 8).cuda(), want_margin=True)
+    torch.cuda.synchronize()
+    assert idx.numel() == 0 and float(loss) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.int64, torch.int32, torch.uint8])
+def test_vq_index_dtypes(amd, oracle, dtype):
+    z, embed = oracle.make_vq_case(16, 200, 512, seed=2)
+    _, idx, _, _ = run_hip(amd, z, embed, idx_dtype=dtype)
+    oidx, _, _ = oracle.vq_argmin_p4(z, embed)
+    assert idx.dtype == dtype and torch.equal(idx.to(torch.int64), oidx)
+
+
+def test_vq_full_size_properties(amd, oracle):
+    """BASELINE config #2 size (262,144 rows, K=256, D=128): the oracle needs ~10 s for all rows on
+    16 cores, so check size-independent properties on every row and the oracle on a 1/32 sample."""
+    N, D, K = 256 * 1024, 128, 256
+    g = torch.Generator().manual_seed(11)
+    embed = torch.randn(K, D, generator=g)
+    z = torch.randn(N, D, generator=g)
+    z[:K] = embed                                   # idempotence: codes map to themselves
+    zc, ec = z.cuda(), embed.cuda()
+    q, idx, loss, margin = amd.ops.vq_forward(zc, ec, 1.0, want_margin=True)
+    torch.cuda.synchronize()
+    assert torch.equal(idx[:K].cpu(), torch.arange(K))
+    assert torch.equal(q, zc + (ec[idx] - zc))     # lookup + straight-through, every row
+    # chosen code is no farther (p=4 sums, fp64) than 64 random other codes, every row
+    d_best = ((zc - ec[idx]).double() ** 4).sum(1)
+    for t in range(4):
+        other = torch.randint(0, K, (N,), device="cuda", generator=None)
+        d_o = ((zc - ec[other]).double() ** 4).sum(1)
+        assert bool((d_best <= d_o * (1 + 1e-6)).all())
+    sel = torch.arange(0, N, 32)
+    oidx, _, _ = oracle.vq_argmin_p4(z[sel], embed)
+    assert torch.equal(idx.cpu()[sel], oidx)
+    ref_loss = float(((zc - ec[idx]).double() ** 2).mean())
+    assert abs(float(loss) - ref_loss) <= 2e-6 * ref_loss
+
+
+def test_embed_code(amd):
+    embed = torch.randn(37, 24)
+    idx = torch.randint(0, 37, (5, 6, 7))
+    out = amd.ops.embed_code(idx.cuda(), embed.cuda()).cpu()
+    assert torch.equal(out, torch.nn.functional.embedding(idx, embed))
+
+
+def test_ema_bookkeeping_matches_golden(amd, oracle):
+    """Training-mode VQ (vq.py:47-94) against the reference-recorded fixture."""
+    from vqae_amd.layers.vq import EMAVectorQuantizer
+    g = load_golden("ema")
+    D, K = int(g["D"]), int(g["K"])
+    z0, embed = oracle.make_vq_case(D, K, 1024, seed=3, adversarial=False)
+    z1, _ = oracle.make_vq_case(D, K, 1024, seed=4, adversarial=False)
+    vq = EMAVectorQuantizer(K, D, 1.0, 0.99, 1e-5).cuda().train()
+    vq.embed.copy_(embed.cuda()); vq.embed_avg.copy_(embed.cuda())
+    for step, z in enumerate((z0 * 1.7 + 0.3, z1 * 1.7 + 0.3)):
+        zin = z.reshape(1, 32, 32, D).permute(0, 3, 1, 2).contiguous().cuda()
+        q, idx, loss = vq(zin)
+        torch.cuda.synchronize()
+        assert np.array_equal(idx.reshape(-1).cpu().numpy(), g[f"idx{step}"].astype(np.int64))
+        np.testing.assert_allclose(vq.embed.cpu().numpy(), g[f"embed{step}"], rtol=2e-6, atol=1e-6)
+        np.testing.assert_allclose(vq.embed_avg.cpu().numpy(), g[f"embed_avg{step}"], rtol=2e-6, atol=1e-6)
+        np.testing.assert_allclose(vq.cluster_size.cpu().numpy(), g[f"cluster_size{step}"], rtol=2e-6, atol=1e-6)
+        assert abs(float(loss) - float(g[f"loss{step}"])) <= 2e-6 * float(g[f"loss{step}"])
+    assert int(vq.first_pass) == 0

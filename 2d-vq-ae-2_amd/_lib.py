@@ -76,6 +76,8 @@ SYMBOLS = {
     "vqae_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
                              c_void_p]),
     "vqae_flops_per_patch": (c_double, [c_void_p, c_int, c_int, c_int, c_int]),
+    "vqae_prof_begin": (c_int, [c_int, c_int]),
+    "vqae_prof_end": (c_int, [POINTER(c_double), POINTER(c_int)]),
 }
 
 _lib = None

@@ -35,6 +35,31 @@ inline int fail(int code, const char* fmt, ...) {
         if (!(cond)) return ::vqae::fail(code, __VA_ARGS__); \
     } while (0)
 
+// ---- optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline) ----
+enum { PROF_NONE = 0, PROF_CONV3X3_TRUNK = 1, PROF_CONV1X1_TRUNK = 2, PROF_VQ_TIER1 = 3 };
+struct ProfState {
+    int cls = 0;
+    int used = 0;
+    int cap = 0;
+    hipEvent_t* ev = nullptr;
+};
+ProfState& prof_state();
+struct ProfScope {
+    bool on;
+    hipStream_t st;
+    ProfScope(int cls, hipStream_t stream) : st(stream) {
+        ProfState& p = prof_state();
+        on = cls != 0 && p.cls == cls && p.used + 2 <= p.cap;
+        if (on) (void)hipEventRecord(p.ev[p.used], st);
+    }
+    void done() {
+        if (!on) return;
+        ProfState& p = prof_state();
+        (void)hipEventRecord(p.ev[p.used + 1], st);
+        p.used += 2;
+    }
+};
+
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
 

@@ -247,7 +247,10 @@ int launch(const ConvK& k, hipStream_t stream) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         attr_set = true;
     }
+    const int cls = (NT == 128 && KC == 32 && k.Cin >= 128) ? (k.ks == 3 ? vqae::PROF_CONV3X3_TRUNK : (k.ks == 1 ? vqae::PROF_CONV1X1_TRUNK : 0)) : 0;
+    vqae::ProfScope prof(cls, stream);
     conv_mfma_kernel<NT, KC><<<grid, 256, lds_bytes, stream>>>(k);
+    prof.done();
     VQAE_LAUNCH_CHECK();
     return VQAE_OK;
 }
@@ -282,7 +285,9 @@ extern "C" int vqae_conv_pack_weight_f32(const float* w, int cout, int cin, int 
 extern "C" int vqae_conv2d_f32(const vqae_conv_args* a, const float* x, const float* w, const float* bias_vec,
                                const float* residual, float* y, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    VQAE_REQUIRE(a && x && w && y, VQAE_ERR_INVALID, "conv2d: null pointer");
+    VQAE_REQUIRE(a, VQAE_ERR_INVALID, "conv2d: null args");
+    if (a->batch == 0) return VQAE_OK;
+    VQAE_REQUIRE(x && w && y, VQAE_ERR_INVALID, "conv2d: null pointer");
     VQAE_REQUIRE(a->cin % 8 == 0 && a->cin >= 8, VQAE_ERR_UNSUPPORTED,
                  "conv2d: cin %d must be a multiple of 8 (use vqae_conv3x3_direct_f32 for stems)", a->cin);
     VQAE_REQUIRE(a->ksize >= 1 && a->ksize <= 3 && (a->stride == 1 || a->stride == 2) && a->pad >= 0 && a->pad <= 1,

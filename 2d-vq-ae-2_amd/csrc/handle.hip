@@ -20,6 +20,47 @@ int conv3x3_direct(const void* x, int x_kind, const float* mean255, const float*
                    hipStream_t stream);
 }  // namespace vqae
 
+namespace vqae {
+ProfState& prof_state() {
+    static ProfState p;
+    return p;
+}
+}  // namespace vqae
+
+extern "C" int vqae_prof_begin(int kernel_class, int max_launches) {
+    vqae::ProfState& p = vqae::prof_state();
+    VQAE_REQUIRE(kernel_class >= 1 && kernel_class <= 3 && max_launches >= 1, VQAE_ERR_INVALID, "prof_begin: bad args");
+    if (p.cap < 2 * max_launches) {
+        for (int i = 0; i < p.cap; ++i) (void)hipEventDestroy(p.ev[i]);
+        delete[] p.ev;
+        p.ev = new hipEvent_t[2 * max_launches];
+        p.cap = 0;
+        for (int i = 0; i < 2 * max_launches; ++i) {
+            VQAE_HIP_CHECK(hipEventCreate(&p.ev[i]));
+            p.cap = i + 1;
+        }
+    }
+    p.used = 0;
+    p.cls = kernel_class;
+    return VQAE_OK;
+}
+
+extern "C" int vqae_prof_end(double* total_ms, int* n_launches) {
+    vqae::ProfState& p = vqae::prof_state();
+    p.cls = 0;
+    double tot = 0.0;
+    for (int i = 0; i + 1 < p.used; i += 2) {
+        VQAE_HIP_CHECK(hipEventSynchronize(p.ev[i + 1]));
+        float ms = 0.f;
+        VQAE_HIP_CHECK(hipEventElapsedTime(&ms, p.ev[i], p.ev[i + 1]));
+        tot += ms;
+    }
+    if (total_ms) *total_ms = tot;
+    if (n_launches) *n_launches = p.used / 2;
+    p.used = 0;
+    return VQAE_OK;
+}
+
 extern "C" const char* vqae_last_error(void) { return vqae::last_error_buf(); }
 extern "C" const char* vqae_build_info(void) { return "gfx950;fp32-mfma;" __DATE__; }
 

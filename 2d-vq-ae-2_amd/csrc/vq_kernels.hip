@@ -351,8 +351,8 @@ extern "C" int vqae_vq_forward_f32(const float* z, const float* embed, int64_t N
                                    void* idx_out, int idx_dtype, float* q, float* loss, float* margin, void* ws,
                                    void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    VQAE_REQUIRE(z && embed && idx_out && ws, VQAE_ERR_INVALID, "vq_forward: null pointer");
     VQAE_REQUIRE(N >= 0 && N < (1ll << 31), VQAE_ERR_INVALID, "vq_forward: n_rows %lld out of range", (long long)N);
+    VQAE_REQUIRE(N == 0 || (z && embed && idx_out && ws), VQAE_ERR_INVALID, "vq_forward: null pointer");
     VQAE_REQUIRE(K >= 1 && K <= 65536, VQAE_ERR_UNSUPPORTED, "vq_forward: n_codes %d unsupported", K);
     VQAE_REQUIRE(D >= 4 && D % 4 == 0 && D <= 4096, VQAE_ERR_UNSUPPORTED, "vq_forward: dim %d must be a multiple of 4", D);
     VQAE_REQUIRE(idx_dtype != VQAE_IDX_U8 || K <= 256, VQAE_ERR_INVALID, "vq_forward: u8 indices need K <= 256");
@@ -381,8 +381,10 @@ extern "C" int vqae_vq_forward_f32(const float* z, const float* embed, int64_t N
         // evaluation-noise bound between tier-1 sums and the reference recipe's sums
         const float thr = (4.0f * (float)D + 16.0f) * 5.9604645e-8f;
         const unsigned grid = (unsigned)vqae::ceil_div(N, VQ_ROWS_PER_BLOCK);
+        vqae::ProfScope prof(vqae::PROF_VQ_TIER1, stream);
         vq_tier1_kernel<<<grid, VQ_WAVES * 64, lds_bytes, stream>>>(z, w.eT, N, K, Kpad, D, thr, w.idx32, margin,
                                                                   w.flag_count, w.flag_list);
+        prof.done();
         VQAE_LAUNCH_CHECK();
     }
     vq_tier2_kernel<<<256, 256, 0, stream>>>(z, embed, K, D, w.idx32, w.flag_count, w.flag_list);

@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the MI355X-native VQ-AE hot path on BASELINE.json's metric.
+
+    python bench.py --gpus N --steps K --warmup W            (N = 1: run directly)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of synthetic patches already resident in HBM:
+VQAE.forward = conv encoder -> p=4 vector quantiser -> conv decoder (reference vq_ae/model.py:41-48)
+on BASELINE.json configs[1]: batch 256 of 256x256x3 fp32 patches -> 32x32 codes, 256-entry/128-dim
+codebook (SURVEY.md §8 "cfg B"), per GPU.  With N > 1 the patch batch is sharded (weak scaling:
+256 patches per rank) and each step ends with the path's only collective, an RCCL all-gather of the
+uint8 code grids.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak (= fp32 vector peak)
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_patches_u8(batch, size, batch_no, device):
+    """uint8 ~ U{0..255} NHWC from PCG64(1000 + batch_no)."""
+    rng = np.random.Generator(np.random.PCG64(1000 + batch_no))
+    return torch.from_numpy(rng.integers(0, 256, size=(batch, size, size, 3), dtype=np.uint8)).to(device)
+
+
+def normalise(u8):
+    """albumentations Normalize + ToTensorV2 -> NCHW fp32 (camelyon16_transforms.yaml:15-23)."""
+    mean = torch.tensor([0.7279, 0.5955, 0.7762], device=u8.device) * 255.0
+    inv = 1.0 / (torch.tensor([0.2419, 0.3083, 0.1741], device=u8.device) * 255.0)
+    return ((u8.float() - mean) * inv).permute(0, 3, 1, 2).contiguous()
+
+
+def synth_weights(spec_name):
+    """Procedural non-zero weights.  bench.py may use the oracle's generator: it is data, not compute."""
+    from oracle import vqae_oracle as O
+    return O.make_params(O.SPECS[spec_name], 0)
+
+
+def cpu_baseline(spec_name, size, params, embed, sample_batch, iters):
+    """The CPU oracle (PyTorch-CPU fp32 restatement of the reference path) timed on this box's host
+    cores, on a bounded sample of the same workload."""
+    from oracle import vqae_oracle as O
+    spec = O.SPECS[spec_name]
+    p = dict(params)
+    p["encoder.vq_layers.0.embed"] = embed.cpu()
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    x = O.make_patches(sample_batch, size, 0)
+    taps = {}
+    O.vqae_forward(x, p, spec, taps)                 # warm-up
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        taps = {}
+        out, _ = O.vqae_forward(x, p, spec, taps)
+    dt = (time.perf_counter() - t0) / iters
+    return dict(value=sample_batch / dt, unit="patches/s", cores=cores, kind="port",
+                sample=f"{iters} x full VQAE.forward of {sample_batch} patches ({size}x{size}x3 fp32), "
+                       f"PyTorch-CPU oracle, {cores} threads"), x, out, taps["idx"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="B", choices=["A", "B", "C"])
+    ap.add_argument("--batch", type=int, default=256, help="patches per GPU per step")
+    ap.add_argument("--mode", default="full", choices=["full", "encode"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prof-class", type=int, default=1, help="kernel class timed for `roofline` (1 = trunk 3x3 conv)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)      # nccl == RCCL on ROCm
+
+    import vqae_amd
+    from vqae_amd import _lib as L
+    size = 512 if args.config == "A" else 256
+    spec = vqae_amd.SPECS[args.config]
+    params = synth_weights(args.config)
+    nat = vqae_amd.NativeVQAE(spec, params)
+    nat.reserve(args.batch, size, size)
+
+    # codebook ~ N(mu_z, sigma_z) of a calibration batch (mirrors _init_ema, vq.py:76-94)
+    calib = normalise(synth_patches_u8(min(args.batch, 8), size, 99, dev))
+    embed = nat.calibrate_codebook(calib, params["encoder.vq_layers.0.embed"])
+
+    x = normalise(synth_patches_u8(args.batch, size, 1000 * rank + 1, dev))     # resident in HBM
+    B = args.batch
+    zh = size // nat.factor
+    idx_dtype = torch.uint8 if spec.num_embeddings <= 256 else torch.int32
+    gathered = torch.empty((world * B, zh, zh), dtype=idx_dtype, device=dev) if world > 1 else None
+
+    def step():
+        if args.mode == "full":
+            out, idx, loss = nat.forward(x, "NCHW", idx_dtype=idx_dtype)
+        else:
+            out = None
+            _, idx, loss = nat.encode(x, "NCHW", idx_dtype=idx_dtype, want_q=False)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, idx)       # reassemble the per-slide code grids
+        return out, idx, loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out, idx, loss = step()
+    barrier()
+
+    # timed region; the dominant kernel class is timed with HIP events on the launch stream
+    lib = L.lib()
+    n_launch_max = args.steps * 256
+    prof_on = rank == 0 and args.prof_class > 0
+    if prof_on:
+        L.check(lib.vqae_prof_begin(args.prof_class, n_launch_max))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, idx, loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    k_ms, k_n = ctypes.c_double(0), ctypes.c_int(0)
+    if prof_on:
+        L.check(lib.vqae_prof_end(ctypes.byref(k_ms), ctypes.byref(k_n)))
+
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total_patches = world * B * args.steps
+        value = total_patches / dt
+        flops_patch = nat.flops_per_patch(size, size, True, args.mode == "full")
+        res = {
+            "metric": "patches/sec (VQAE.forward: encoder -> VQ -> decoder)" if args.mode == "full"
+                      else "patches/sec (Encoder.forward: encoder -> VQ indices)",
+            "value": round(value, 2), "unit": "patches/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1] (cfg {args.config}): batch {B}/GPU of {size}x{size}x3 fp32 "
+                                   f"patches -> {zh}x{zh} codes, K={spec.num_embeddings}, D={spec.code_dim}, "
+                                   f"{args.mode} forward", "global_batch": world * B,
+                       "parallelism": f"patch-sharded x{world}" + (", all-gather of code grids" if world > 1 else "")},
+            "conv_tflops": round(value * flops_patch / 1e12, 2),
+            "recon_mse_vs_input": float(((out - x) ** 2).mean()) if out is not None else None,
+            "vq_loss": float(loss),
+        }
+        # ---- roofline of the dominant kernel ---------------------------------------------------
+        if prof_on and k_n.value > 0:
+            avg_ms = k_ms.value / k_n.value
+            C = spec.channels
+            M = B * zh * zh
+            if args.prof_class == 1:      # trunk 3x3 circular conv: 2*M*N*K flops, N = C, K = 9C
+                alg = 2.0 * M * C * 9 * C
+                res["roofline"] = {"kernel": "conv_mfma_kernel<128,32> (3x3 circular, trunk)", "bound": "mfma",
+                                   "achieved": round(alg / (avg_ms * 1e-3) / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                                   "unit": "TFLOP/s", "traffic": None, "launches": k_n.value,
+                                   "avg_ms": round(avg_ms, 4), "alg_flops_per_launch": alg}
+            elif args.prof_class == 2:
+                alg = 2.0 * M * C * C
+                res["roofline"] = {"kernel": "conv_mfma_kernel<128,32> (1x1, trunk)", "bound": "mfma",
+                                   "achieved": round(alg / (avg_ms * 1e-3) / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                                   "unit": "TFLOP/s", "traffic": None, "launches": k_n.value,
+                                   "avg_ms": round(avg_ms, 4), "alg_flops_per_launch": alg}
+            else:                          # VQ tier 1: algorithmic HBM bytes = N*D*4 read + N idx
+                alg = M * spec.code_dim * 4.0 + M * 4.0
+                res["roofline"] = {"kernel": "vq_tier1_kernel", "bound": "hbm",
+                                   "achieved": round(alg / (avg_ms * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS,
+                                   "unit": "GB/s", "traffic": None, "launches": k_n.value,
+                                   "avg_ms": round(avg_ms, 4), "alg_bytes_per_launch": alg,
+                                   "valu_ops_per_launch": 3.0 * M * spec.num_embeddings * spec.code_dim}
+            res["roofline"]["frac"] = round(res["roofline"]["achieved"] / res["roofline"]["peak"], 4)
+        # ---- CPU baseline beside it (rank 0, N = 1 only) -----------------------------------------
+        if world == 1 and not args.no_cpu_baseline:
+            sb = 4 if size == 256 else 2
+            cb, cx, cout, cidx = cpu_baseline(args.config, size, params, embed, sb, 2)
+            res["cpu_baseline"] = cb
+            g_out, g_idx, _ = nat.forward(cx.to(dev), "NCHW")
+            res["parity_on_cpu_sample"] = {
+                "idx_agreement": float((g_idx.cpu() == cidx).float().mean()),
+                "recon_mse_vs_cpu": float(((g_out.cpu() - cout) ** 2).mean()),
+            }
+        print(json.dumps(res), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -209,6 +209,14 @@ int vqae_forward(vqae_handle* h, const float* x_dev, int batch, int in_h, int in
 /* Introspection for benchmarks: algorithmic FLOPs (2*MACs) of the conv stacks per patch. */
 double vqae_flops_per_patch(const vqae_handle* h, int in_h, int in_w, int encoder, int decoder);
 
+/* ---------------------------------------------------------------------------------------------
+ * 4. Measurement hook (bench.py `roofline`): time every launch of one kernel class with HIP events
+ *    recorded on the launch stream.  kernel_class: 1 = trunk 3x3 circular conv (MFMA, cin >= 128),
+ *    2 = trunk 1x1 conv, 3 = VQ tier-1 argmin.  Not thread-safe; off by default.
+ * ------------------------------------------------------------------------------------------- */
+int vqae_prof_begin(int kernel_class, int max_launches);
+int vqae_prof_end(double* total_ms, int* n_launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,6 +28,22 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_HBM_GBS = 8000.0
 
 
+def host_cores():
+    """CPU share of this process (the GPU box gives 16 cores per GPU; os.cpu_count() reports the host)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, int(os.environ.get("VQAE_CPU_THREADS", "16"))))
+
+
+def log(msg):
+    print(f"[bench +{time.perf_counter() - T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+T0 = time.perf_counter()
+
+
 def synth_patches_u8(batch, size, batch_no, device):
     """uint8 ~ U{0..255} NHWC from PCG64(1000 + batch_no)."""
     rng = np.random.Generator(np.random.PCG64(1000 + batch_no))
@@ -54,7 +70,7 @@ def cpu_baseline(spec_name, size, params, embed, sample_batch, iters):
     spec = O.SPECS[spec_name]
     p = dict(params)
     p["encoder.vq_layers.0.embed"] = embed.cpu()
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     x = O.make_patches(sample_batch, size, 0)
     taps = {}
@@ -98,8 +114,10 @@ def main():
     size = 512 if args.config == "A" else 256
     spec = vqae_amd.SPECS[args.config]
     params = synth_weights(args.config)
+    log("weights generated")
     nat = vqae_amd.NativeVQAE(spec, params)
     nat.reserve(args.batch, size, size)
+    log("native handle created, workspace reserved")
 
     # codebook ~ N(mu_z, sigma_z) of a calibration batch (mirrors _init_ema, vq.py:76-94)
     calib = normalise(synth_patches_u8(min(args.batch, 8), size, 99, dev))
@@ -126,9 +144,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    log("codebook calibrated, inputs resident")
     for _ in range(args.warmup):
         out, idx, loss = step()
     barrier()
+    log("warm-up done")
 
     # timed region; the dominant kernel class is timed with HIP events on the launch stream
     lib = L.lib()
@@ -142,6 +162,7 @@ def main():
         out, idx, loss = step()
     barrier()
     dt = time.perf_counter() - t0
+    log(f"timed region done: {dt / args.steps * 1e3:.2f} ms/step")
     k_ms, k_n = ctypes.c_double(0), ctypes.c_int(0)
     if prof_on:
         L.check(lib.vqae_prof_end(ctypes.byref(k_ms), ctypes.byref(k_n)))
@@ -197,7 +218,9 @@ def main():
         # ---- CPU baseline beside it (rank 0, N = 1 only) -----------------------------------------
         if world == 1 and not args.no_cpu_baseline:
             sb = 4 if size == 256 else 2
+            log("cpu baseline ...")
             cb, cx, cout, cidx = cpu_baseline(args.config, size, params, embed, sb, 2)
+            log("cpu baseline done")
             res["cpu_baseline"] = cb
             g_out, g_idx, _ = nat.forward(cx.to(dev), "NCHW")
             res["parity_on_cpu_sample"] = {

@@ -22,6 +22,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvK {
     const float* __restrict__ x;
@@ -38,6 +39,74 @@ struct ConvK {
 };
 
 __device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : expm1f(v); }
+
+// Branch-free gather of step s into registers: every lane always loads from a valid (wrapped or
+// clamped) address so the loads stay in flight under the MFMAs of the current step; zero padding is
+// applied by a select when the tile is written to LDS.
+template <int A_PT, int B_PT, int NT, int KC>
+__device__ __forceinline__ void conv_load_step(const ConvK& p, int s, int tid, int n0, int a_c4,
+                                               const int (&a_oy)[A_PT], const int (&a_ox)[A_PT],
+                                               const int64_t (&a_img)[A_PT], f32x4 (&ra)[A_PT], f32x4 (&rb)[B_PT],
+                                               unsigned& ra_zero) {
+    constexpr int C4 = KC / 4;
+    constexpr int B_F4 = NT * KC / 4;
+    const int tap = s / p.n_chunks, chunk = s - tap * p.n_chunks;
+    const int dy = tap / p.ks, dx = tap - dy * p.ks;
+    const bool circ = p.pad_mode == VQAE_PAD_CIRCULAR;
+    unsigned z = 0;
+#pragma unroll
+    for (int i = 0; i < A_PT; ++i) {
+        const int iy0 = a_oy[i] * p.stride + dy - p.pad;
+        const int ix0 = a_ox[i] * p.stride + dx - p.pad;
+        const int wy = iy0 < 0 ? iy0 + p.H : (iy0 >= p.H ? iy0 - p.H : iy0);      // circular wrap
+        const int wx = ix0 < 0 ? ix0 + p.W : (ix0 >= p.W ? ix0 - p.W : ix0);
+        const int cy = iy0 < 0 ? 0 : (iy0 >= p.H ? p.H - 1 : iy0);                // clamp (value zeroed later)
+        const int cx = ix0 < 0 ? 0 : (ix0 >= p.W ? p.W - 1 : ix0);
+        const bool oob = (iy0 != cy) | (ix0 != cx);
+        z |= (!circ && oob) ? (1u << i) : 0u;
+        const int iy = circ ? wy : cy, ix = circ ? wx : cx;
+        const float* src = p.x + ((a_img[i] + (int64_t)iy * p.W + ix) * p.Cin + chunk * KC + a_c4 * 4);
+        ra[i] = *reinterpret_cast<const f32x4*>(src);
+    }
+    ra_zero = z;
+#pragma unroll
+    for (int i = 0; i < B_PT; ++i) {
+        const int f = tid + i * 256;
+        const int fc = (B_F4 % 256 == 0 || f < B_F4) ? f : 0;
+        const int n = fc / C4, c4 = fc % C4;
+        rb[i] = *reinterpret_cast<const f32x4*>(p.w + (int64_t)(n0 + n) * p.Ktot + (int64_t)s * KC + c4 * 4);
+    }
+}
+
+template <int A_PT, int B_PT, int NT, int KC>
+__device__ __forceinline__ void conv_store_step(const ConvK& p, float* As, float* Bs, int tid, int a_c4,
+                                                const int (&a_row)[A_PT], const f32x4 (&ra)[A_PT],
+                                                const f32x4 (&rb)[B_PT], unsigned ra_zero) {
+    constexpr int LDR = KC + 4;
+    constexpr int C4 = KC / 4;
+    constexpr int B_F4 = NT * KC / 4;
+#pragma unroll
+    for (int i = 0; i < A_PT; ++i) {
+        f32x4 v = ra[i];
+        if (p.pre_mode != VQAE_PRE_NONE) {
+            v = v + p.pre_a;
+            if (p.pre_mode == VQAE_PRE_BIAS_ELU_BIAS) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = elu1(v[e]) + p.pre_b;
+            }
+        }
+        if ((ra_zero >> i) & 1u) v = (f32x4)(0.f);
+        *reinterpret_cast<f32x4*>(As + a_row[i] * LDR + a_c4 * 4) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PT; ++i) {
+        const int f = tid + i * 256;
+        if (B_F4 % 256 == 0 || f < B_F4) {
+            const int n = f / C4, c4 = f % C4;
+            *reinterpret_cast<f32x4*>(Bs + n * LDR + c4 * 4) = rb[i];
+        }
+    }
+}
 
 template <int NT, int KC>
 __global__ __launch_bounds__(256, 2)
@@ -76,14 +145,12 @@ void conv_mfma_kernel(const ConvK p) {
     const int a_c4 = tid % C4;
     int a_row[A_PT], a_oy[A_PT], a_ox[A_PT];
     int64_t a_img[A_PT];
-    bool a_ok[A_PT];
 #pragma unroll
     for (int i = 0; i < A_PT; ++i) {
         const int row = tid / C4 + i * (256 / C4);
         a_row[i] = row;
         const int m = m0 + row;
-        a_ok[i] = m < p.M;
-        const int mm = a_ok[i] ? m : 0;
+        const int mm = m < p.M ? m : 0;             // tail rows gather pixel 0 (their stores are masked)
         const int hw = p.Ho * p.Wo;
         const int b = mm / hw, rem = mm - b * hw;
         a_oy[i] = rem / p.Wo;
@@ -91,65 +158,8 @@ void conv_mfma_kernel(const ConvK p) {
         a_img[i] = (int64_t)b * p.H * p.W;
     }
 
-    float4 ra[A_PT], rb[B_PT];
-    bool ra_valid[A_PT];
-
-    auto load_global = [&](int s) {
-        const int tap = s / p.n_chunks, chunk = s - tap * p.n_chunks;
-        const int dy = tap / p.ks, dx = tap - dy * p.ks;
-#pragma unroll
-        for (int i = 0; i < A_PT; ++i) {
-            int iy = a_oy[i] * p.stride + dy - p.pad;
-            int ix = a_ox[i] * p.stride + dx - p.pad;
-            bool ok = a_ok[i];
-            if (p.pad_mode == VQAE_PAD_CIRCULAR) {
-                iy = iy < 0 ? iy + p.H : (iy >= p.H ? iy - p.H : iy);
-                ix = ix < 0 ? ix + p.W : (ix >= p.W ? ix - p.W : ix);
-            } else {
-                ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            }
-            ra_valid[i] = ok;
-            if (ok) {
-                const float* src = p.x + ((a_img[i] + (int64_t)iy * p.W + ix) * p.Cin + chunk * KC + a_c4 * 4);
-                ra[i] = *reinterpret_cast<const float4*>(src);
-            } else {
-                ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < B_PT; ++i) {
-            const int f = tid + i * 256;
-            if (B_F4 % 256 == 0 || f < B_F4) {
-                const int n = f / C4, c4 = f % C4;
-                rb[i] = *reinterpret_cast<const float4*>(p.w + (int64_t)(n0 + n) * p.Ktot + (int64_t)s * KC + c4 * 4);
-            }
-        }
-    };
-
-    auto store_lds = [&](int buf) {
-        float* As = Abuf0 + buf * 128 * LDR;
-        float* Bs = Bbuf0 + buf * NT * LDR;
-#pragma unroll
-        for (int i = 0; i < A_PT; ++i) {
-            float4 v = ra[i];
-            if (p.pre_mode != VQAE_PRE_NONE && ra_valid[i]) {
-                v.x += p.pre_a; v.y += p.pre_a; v.z += p.pre_a; v.w += p.pre_a;
-                if (p.pre_mode == VQAE_PRE_BIAS_ELU_BIAS) {
-                    v.x = elu1(v.x) + p.pre_b; v.y = elu1(v.y) + p.pre_b;
-                    v.z = elu1(v.z) + p.pre_b; v.w = elu1(v.w) + p.pre_b;
-                }
-            }
-            *reinterpret_cast<float4*>(As + a_row[i] * LDR + a_c4 * 4) = v;
-        }
-#pragma unroll
-        for (int i = 0; i < B_PT; ++i) {
-            const int f = tid + i * 256;
-            if (B_F4 % 256 == 0 || f < B_F4) {
-                const int n = f / C4, c4 = f % C4;
-                *reinterpret_cast<float4*>(Bs + n * LDR + c4 * 4) = rb[i];
-            }
-        }
-    };
+    f32x4 ra[A_PT], rb[B_PT];
+    unsigned ra_zero = 0;            // bit i: tap of pixel i fell into the zero padding
 
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -162,13 +172,14 @@ void conv_mfma_kernel(const ConvK p) {
     const int frag_row = lane & 31;
     const int frag_k = 4 * (lane >> 5);
 
-    load_global(0);
-    store_lds(0);
+    conv_load_step<A_PT, B_PT, NT, KC>(p, 0, tid, n0, a_c4, a_oy, a_ox, a_img, ra, rb, ra_zero);
+    conv_store_step<A_PT, B_PT, NT, KC>(p, Abuf0, Bbuf0, tid, a_c4, a_row, ra, rb, ra_zero);
     __syncthreads();
 
     for (int s = 0; s < p.n_steps; ++s) {
         const int buf = s & 1;
-        if (s + 1 < p.n_steps) load_global(s + 1);
+        if (s + 1 < p.n_steps)
+            conv_load_step<A_PT, B_PT, NT, KC>(p, s + 1, tid, n0, a_c4, a_oy, a_ox, a_img, ra, rb, ra_zero);
 
         const float* As = Abuf0 + buf * 128 * LDR + (wm * MI * 32 + frag_row) * LDR + frag_k;
         const float* Bs = Bbuf0 + buf * NT * LDR + (wn * NI * 32 + frag_row) * LDR + frag_k;
@@ -177,13 +188,13 @@ void conv_mfma_kernel(const ConvK p) {
             float a[MI][4], b[NI][4];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
-                const float4 v = *reinterpret_cast<const float4*>(As + mi * 32 * LDR + 8 * u);
-                a[mi][0] = v.x; a[mi][1] = v.y; a[mi][2] = v.z; a[mi][3] = v.w;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(As + mi * 32 * LDR + 8 * u);
+                a[mi][0] = v[0]; a[mi][1] = v[1]; a[mi][2] = v[2]; a[mi][3] = v[3];
             }
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-                const float4 v = *reinterpret_cast<const float4*>(Bs + ni * 32 * LDR + 8 * u);
-                b[ni][0] = v.x; b[ni][1] = v.y; b[ni][2] = v.z; b[ni][3] = v.w;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(Bs + ni * 32 * LDR + 8 * u);
+                b[ni][0] = v[0]; b[ni][1] = v[1]; b[ni][2] = v[2]; b[ni][3] = v[3];
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -194,7 +205,9 @@ void conv_mfma_kernel(const ConvK p) {
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][r], b[ni][r], acc[mi][ni], 0, 0, 0);
         }
 
-        if (s + 1 < p.n_steps) store_lds(buf ^ 1);
+        if (s + 1 < p.n_steps)
+            conv_store_step<A_PT, B_PT, NT, KC>(p, Abuf0 + (buf ^ 1) * 128 * LDR, Bbuf0 + (buf ^ 1) * NT * LDR, tid,
+                                                a_c4, a_row, ra, rb, ra_zero);
         __syncthreads();
     }
 

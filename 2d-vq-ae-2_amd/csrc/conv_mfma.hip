@@ -38,7 +38,25 @@ struct ConvK {
     float scale, bias_s, act_a, act_b;
 };
 
-__device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : expm1f(v); }
+// ELU(alpha = 1) = v > 0 ? v : expm1(v), branch-free so the Fixup pre-op / epilogue can be scheduled
+// between MFMAs: expm1(x) for x <= 0 as 2^k * expm1(r) + (2^k - 1), x = k ln2 + r, |r| <= ln2/2,
+// expm1(r) by a degree-7 Taylor polynomial (truncation < 1e-8 relative): <= ~1.5 ulp of the result.
+__device__ __forceinline__ float elu1(float v) {
+    const float x = fmaxf(fminf(v, 0.f), -88.f);
+    const float k = __builtin_rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(k, -0.693145751953125f, x);
+    r = __builtin_fmaf(k, -1.42860682030941723e-06f, r);
+    float p = 1.98412698e-04f;
+    p = __builtin_fmaf(p, r, 1.38888889e-03f);
+    p = __builtin_fmaf(p, r, 8.33333333e-03f);
+    p = __builtin_fmaf(p, r, 4.16666667e-02f);
+    p = __builtin_fmaf(p, r, 1.66666667e-01f);
+    p = __builtin_fmaf(p, r, 0.5f);
+    const float em = __builtin_fmaf(p * r, r, r);
+    const float sc = __builtin_ldexpf(1.0f, (int)k);
+    const float e = __builtin_fmaf(sc, em, sc - 1.0f);
+    return v > 0.f ? v : e;
+}
 
 // Branch-free gather of step s into registers: every lane always loads from a valid (wrapped or
 // clamped) address so the loads stay in flight under the MFMAs of the current step; zero padding is
@@ -176,26 +194,16 @@ void conv_mfma_kernel(const ConvK p) {
     conv_store_step<A_PT, B_PT, NT, KC>(p, Abuf0, Bbuf0, tid, a_c4, a_row, ra, rb, ra_zero);
     __syncthreads();
 
-    for (int s = 0; s < p.n_steps; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < p.n_steps)
-            conv_load_step<A_PT, B_PT, NT, KC>(p, s + 1, tid, n0, a_c4, a_oy, a_ox, a_img, ra, rb, ra_zero);
-
+    auto compute = [&](int buf) {
         const float* As = Abuf0 + buf * 128 * LDR + (wm * MI * 32 + frag_row) * LDR + frag_k;
         const float* Bs = Bbuf0 + buf * NT * LDR + (wn * NI * 32 + frag_row) * LDR + frag_k;
 #pragma unroll
         for (int u = 0; u < KC / 8; ++u) {
-            float a[MI][4], b[NI][4];
+            f32x4 a[MI], b[NI];
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(As + mi * 32 * LDR + 8 * u);
-                a[mi][0] = v[0]; a[mi][1] = v[1]; a[mi][2] = v[2]; a[mi][3] = v[3];
-            }
+            for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(As + mi * 32 * LDR + 8 * u);
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(Bs + ni * 32 * LDR + 8 * u);
-                b[ni][0] = v[0]; b[ni][1] = v[1]; b[ni][2] = v[2]; b[ni][3] = v[3];
-            }
+            for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(Bs + ni * 32 * LDR + 8 * u);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -204,36 +212,52 @@ void conv_mfma_kernel(const ConvK p) {
                     for (int ni = 0; ni < NI; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][r], b[ni][r], acc[mi][ni], 0, 0, 0);
         }
+    };
 
-        if (s + 1 < p.n_steps)
-            conv_store_step<A_PT, B_PT, NT, KC>(p, Abuf0 + (buf ^ 1) * 128 * LDR, Bbuf0 + (buf ^ 1) * NT * LDR, tid,
-                                                a_c4, a_row, ra, rb, ra_zero);
+    // main loop (last step peeled so the body is branch-free: gather s+1 -> MFMAs of s -> LDS store of s+1)
+    const int last = p.n_steps - 1;
+    for (int s = 0; s < last; ++s) {
+        const int buf = s & 1;
+        conv_load_step<A_PT, B_PT, NT, KC>(p, s + 1, tid, n0, a_c4, a_oy, a_ox, a_img, ra, rb, ra_zero);
+        __builtin_amdgcn_sched_barrier(0);      // keep the gather ahead of the MFMAs (hipcc sinks it otherwise)
+        compute(buf);
+        __builtin_amdgcn_sched_barrier(0);
+        conv_store_step<A_PT, B_PT, NT, KC>(p, Abuf0 + (buf ^ 1) * 128 * LDR, Bbuf0 + (buf ^ 1) * NT * LDR, tid,
+                                            a_c4, a_row, ra, rb, ra_zero);
         __syncthreads();
     }
+    compute(last & 1);
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     const int col = lane & 31;
     const int rhalf = 4 * (lane >> 5);
+    const bool full_tile = (m0 + 128 <= p.M) && (n0 + NT <= p.Cout);     // wave-uniform fast path
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
         const int n = n0 + wn * NI * 32 + ni * 32 + col;
-        const bool n_ok = n < p.Cout;
+        const bool n_ok = full_tile || n < p.Cout;
         const float bv = (p.bias_vec && n_ok) ? p.bias_vec[n] : 0.f;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
+            const int mb = m0 + wm * MI * 32 + mi * 32 + rhalf;
+            float res[16];
+            if (p.residual) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    res[r] = (full_tile || (n_ok && m < p.M)) ? p.residual[(int64_t)m * p.Cout + n] : 0.f;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * MI * 32 + mi * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
-                if (n_ok && m < p.M) {
-                    float t = acc[mi][ni][r];
-                    if (p.has_scale) { t = t * p.scale; t = t + p.bias_s; }
-                    else if (p.has_bias_s) { t = t + p.bias_s; }
-                    if (p.bias_vec) t = t + bv;
-                    const int64_t o = (int64_t)m * p.Cout + n;
-                    if (p.residual) t = t + p.residual[o];
-                    if (p.has_act) t = elu1(t + p.act_a) + p.act_b;
-                    p.y[o] = t;
-                }
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                float t = acc[mi][ni][r];
+                if (p.has_scale) { t = t * p.scale; t = t + p.bias_s; }
+                else if (p.has_bias_s) { t = t + p.bias_s; }
+                if (p.bias_vec) t = t + bv;
+                if (p.residual) t = t + res[r];
+                if (p.has_act) t = elu1(t + p.act_a) + p.act_b;
+                if (full_tile || (n_ok && m < p.M)) p.y[(int64_t)m * p.Cout + n] = t;
             }
         }
     }

@@ -1,0 +1,60 @@
+"""GPU: whole-slide driver (run_eval / get_encodings mirrors) against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def test_get_encodings_synthetic_slides(amd, oracle):
+    from vqae_amd.extract_embeddings import SyntheticSlideDataset, cast_to_lowest_dtype, get_encodings, run_eval
+    g = load_golden("model_tiny")
+    spec = oracle.SPECS["tiny"]
+    p = oracle.make_params(spec, 0)
+    p["encoder.vq_layers.0.embed"] = torch.from_numpy(g["embed"])
+    nat = amd.NativeVQAE(amd.SPECS["tiny"], p)
+    ds = SyntheticSlideDataset([(3, 2), (2, 3)], patch_size=32, raw=True, names=["a", "b"])
+    grids = dict(get_encodings(nat, ds, batch_size=5))             # batches straddle the two slides
+    assert set(grids) == {"images/a", "images/b", "masks/a_mask", "masks/b_mask"}
+    # oracle: encode every tile on the CPU and stitch
+    for s, name in enumerate(["a", "b"]):
+        rows, cols = ds._sizes[s]
+        tiles, labs = [], []
+        for i in range(len(ds)):
+            if ds.locate(i)[0] != s:
+                continue
+            img, lab, _ = ds[i]
+            x = oracle.normalize_u8(img.numpy()[None])
+            (_,), (idx,), _ = oracle.encoder_forward(x, p, spec)
+            tiles.append(idx[0].numpy())
+            labs.append(oracle.adaptive_max_pool_labels(lab.numpy(), 8)[0])
+        want = oracle.cast_to_lowest_dtype(oracle.stitch_slide(np.stack(tiles), rows, cols))
+        got = grids[f"images/{name}"]
+        assert got.shape == (rows * 8, cols * 8) and got.dtype == want.dtype
+        assert np.array_equal(got, want)
+        wantm = oracle.cast_to_lowest_dtype(oracle.stitch_slide(np.stack(labs), rows, cols))
+        assert np.array_equal(grids[f"masks/{name}_mask"], wantm) and grids[f"masks/{name}_mask"].dtype == wantm.dtype
+    # reference yield contract of run_eval: ((idx, names, img_index, patch_index), (labels, ...))
+    first = next(iter(run_eval(nat, ds, batch_size=4)))
+    (idx, names, ii, pi), (lab, lnames, _, _) = tuple(first)
+    assert idx.dtype == torch.int64 and idx.shape == (4, 8, 8) and names[0] == "images/a" and lnames[0] == "masks/a_mask"
+    assert pi.shape == (4, 2) and lab.shape == (4, 8, 8)
+
+
+def test_module_mirror_works_with_driver(amd, oracle):
+    from vqae_amd.extract_embeddings import SyntheticSlideDataset, get_encodings
+    from vqae_amd.model import VQAE
+    g = load_golden("model_tiny")
+    p = oracle.make_params(oracle.SPECS["tiny"], 0)
+    p["encoder.vq_layers.0.embed"] = torch.from_numpy(g["embed"])
+    model = VQAE.from_spec(amd.SPECS["tiny"])
+    model.load_state_dict(p, strict=False)
+    model = model.cuda().eval()
+    ds = SyntheticSlideDataset([(2, 2)], patch_size=32, raw=False)
+    grids = dict(get_encodings(model, ds, batch_size=3))
+    nat = amd.NativeVQAE(amd.SPECS["tiny"], p)
+    ds_raw = SyntheticSlideDataset([(2, 2)], patch_size=32, raw=True)
+    grids_raw = dict(get_encodings(nat, ds_raw, batch_size=3))
+    assert np.array_equal(grids["images/slide_000"], grids_raw["images/slide_000"])

@@ -18,6 +18,7 @@
 // reads 4 consecutive k at 8u + 4h and feeds them to 4 consecutive MFMAs; A and B use the same k
 // permutation, which the sum over k does not see.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -58,75 +59,19 @@ __device__ __forceinline__ float elu1(float v) {
     return v > 0.f ? v : e;
 }
 
-// Branch-free gather of step s into registers: every lane always loads from a valid (wrapped or
-// clamped) address so the loads stay in flight under the MFMAs of the current step; zero padding is
-// applied by a select when the tile is written to LDS.
-template <int A_PT, int B_PT, int NT, int KC>
-__device__ __forceinline__ void conv_load_step(const ConvK& p, int s, int tid, int n0, int a_c4,
-                                               const int (&a_oy)[A_PT], const int (&a_ox)[A_PT],
-                                               const int64_t (&a_img)[A_PT], f32x4 (&ra)[A_PT], f32x4 (&rb)[B_PT],
-                                               unsigned& ra_zero) {
-    constexpr int C4 = KC / 4;
-    constexpr int B_F4 = NT * KC / 4;
-    const int tap = s / p.n_chunks, chunk = s - tap * p.n_chunks;
-    const int dy = tap / p.ks, dx = tap - dy * p.ks;
-    const bool circ = p.pad_mode == VQAE_PAD_CIRCULAR;
-    unsigned z = 0;
-#pragma unroll
-    for (int i = 0; i < A_PT; ++i) {
-        const int iy0 = a_oy[i] * p.stride + dy - p.pad;
-        const int ix0 = a_ox[i] * p.stride + dx - p.pad;
-        const int wy = iy0 < 0 ? iy0 + p.H : (iy0 >= p.H ? iy0 - p.H : iy0);      // circular wrap
-        const int wx = ix0 < 0 ? ix0 + p.W : (ix0 >= p.W ? ix0 - p.W : ix0);
-        const int cy = iy0 < 0 ? 0 : (iy0 >= p.H ? p.H - 1 : iy0);                // clamp (value zeroed later)
-        const int cx = ix0 < 0 ? 0 : (ix0 >= p.W ? p.W - 1 : ix0);
-        const bool oob = (iy0 != cy) | (ix0 != cx);
-        z |= (!circ && oob) ? (1u << i) : 0u;
-        const int iy = circ ? wy : cy, ix = circ ? wx : cx;
-        const float* src = p.x + ((a_img[i] + (int64_t)iy * p.W + ix) * p.Cin + chunk * KC + a_c4 * 4);
-        ra[i] = *reinterpret_cast<const f32x4*>(src);
-    }
-    ra_zero = z;
-#pragma unroll
-    for (int i = 0; i < B_PT; ++i) {
-        const int f = tid + i * 256;
-        const int fc = (B_F4 % 256 == 0 || f < B_F4) ? f : 0;
-        const int n = fc / C4, c4 = fc % C4;
-        rb[i] = *reinterpret_cast<const f32x4*>(p.w + (int64_t)(n0 + n) * p.Ktot + (int64_t)s * KC + c4 * 4);
-    }
-}
-
-template <int A_PT, int B_PT, int NT, int KC>
-__device__ __forceinline__ void conv_store_step(const ConvK& p, float* As, float* Bs, int tid, int a_c4,
-                                                const int (&a_row)[A_PT], const f32x4 (&ra)[A_PT],
-                                                const f32x4 (&rb)[B_PT], unsigned ra_zero) {
-    constexpr int LDR = KC + 4;
-    constexpr int C4 = KC / 4;
-    constexpr int B_F4 = NT * KC / 4;
-#pragma unroll
-    for (int i = 0; i < A_PT; ++i) {
-        f32x4 v = ra[i];
-        if (p.pre_mode != VQAE_PRE_NONE) {
-            v = v + p.pre_a;
-            if (p.pre_mode == VQAE_PRE_BIAS_ELU_BIAS) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = elu1(v[e]) + p.pre_b;
-            }
-        }
-        if ((ra_zero >> i) & 1u) v = (f32x4)(0.f);
-        *reinterpret_cast<f32x4*>(As + a_row[i] * LDR + a_c4 * 4) = v;
-    }
-#pragma unroll
-    for (int i = 0; i < B_PT; ++i) {
-        const int f = tid + i * 256;
-        if (B_F4 % 256 == 0 || f < B_F4) {
-            const int n = f / C4, c4 = f % C4;
-            *reinterpret_cast<f32x4*>(Bs + n * LDR + c4 * 4) = rb[i];
-        }
-    }
-}
-
-template <int NT, int KC>
+// ------------------------------------------------------------------------------------------------
+// fp32 MFMA and VALU instructions do not co-execute on gfx950 (SQ_VALU_MFMA_COEXEC_CYCLES = 0 for this
+// kernel; the f32 MFMA runs on the fp32 vector datapath), so every VALU instruction in the K loop is
+// paid in matrix-pipe time.  The loop is therefore written to issue almost none:
+//   * all per-pixel gather geometry (wrapped / clamped row and column offsets of every tap, zero-pad
+//     bits) is computed once per workgroup into registers; a K-step costs no address arithmetic --
+//     loads use a wave-uniform base (SGPR: image base + channel chunk) plus a 32-bit lane offset that
+//     only changes when the tap changes (one add per pixel per tap);
+//   * the loop is unrolled over the two LDS buffers so every ds_read / ds_write address is
+//     base VGPR + immediate;
+//   * the epilogue addresses through buffer descriptors (hardware range check drops the M tail).
+// ------------------------------------------------------------------------------------------------
+template <int NT, int KC, int PRE, bool PADZ>
 __global__ __launch_bounds__(256, 2)
 void conv_mfma_kernel(const ConvK p) {
     constexpr int LDR = KC + 4;                      // LDS row stride (floats)
@@ -138,10 +83,12 @@ void conv_mfma_kernel(const ConvK p) {
     constexpr int B_F4 = NT * KC / 4;                // float4 in the B tile
     constexpr int B_PT = (B_F4 + 255) / 256;
     constexpr int C4 = KC / 4;                       // float4 per tile row
+    constexpr int A_BUF = 128 * LDR;                 // floats per A buffer
+    constexpr int B_BUF = NT * LDR;
 
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 * (128 + NT) * LDR floats
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // A0 A1 B0 B1
     float* const Abuf0 = lds;
-    float* const Bbuf0 = lds + 2 * 128 * LDR;
+    float* const Bbuf0 = lds + 2 * A_BUF;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -159,25 +106,105 @@ void conv_mfma_kernel(const ConvK p) {
     const int m0 = tile_m * 128;
     const int n0 = blockIdx.y * NT;
 
-    // per-thread A-gather bookkeeping: A_PT pixels, one float4 column each
+    // ---- one-time gather geometry ----------------------------------------------------------------
+    const int hw_o = p.Ho * p.Wo;
+    const int img0 = m0 / hw_o;                                              // wave-uniform
+    const float* const xb = p.x + (int64_t)img0 * p.H * p.W * p.Cin;         // uniform base of this tile's images
+    const bool circ = p.pad_mode == VQAE_PAD_CIRCULAR;
     const int a_c4 = tid % C4;
-    int a_row[A_PT], a_oy[A_PT], a_ox[A_PT];
-    int64_t a_img[A_PT];
+    int yo0[A_PT], yo1[A_PT], yo2[A_PT], xo0[A_PT], xo1[A_PT], xo2[A_PT];   // element offsets (relative to xb) per tap row / column
+    unsigned zbits[A_PT];                            // bit (3*dy + dx): tap lies in the zero padding
+    int a_wr[A_PT];                                  // LDS write offset (floats) of this thread's A pieces
 #pragma unroll
     for (int i = 0; i < A_PT; ++i) {
         const int row = tid / C4 + i * (256 / C4);
-        a_row[i] = row;
-        const int m = m0 + row;
-        const int mm = m < p.M ? m : 0;             // tail rows gather pixel 0 (their stores are masked)
-        const int hw = p.Ho * p.Wo;
-        const int b = mm / hw, rem = mm - b * hw;
-        a_oy[i] = rem / p.Wo;
-        a_ox[i] = rem - a_oy[i] * p.Wo;
-        a_img[i] = (int64_t)b * p.H * p.W;
+        a_wr[i] = row * LDR + a_c4 * 4;
+        int m = m0 + row;
+        m = m < p.M ? m : p.M - 1;                   // tail rows re-gather the last pixel; their stores are dropped
+        const int b = m / hw_o, rem = m - b * hw_o;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        const int imgoff = (b - img0) * p.H * p.W * p.Cin;
+        unsigned zy = 0, zx = 0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int iy0 = oy * p.stride + d - p.pad, ix0 = ox * p.stride + d - p.pad;
+            const int wy = iy0 < 0 ? iy0 + p.H : (iy0 >= p.H ? iy0 - p.H : iy0);
+            const int wx = ix0 < 0 ? ix0 + p.W : (ix0 >= p.W ? ix0 - p.W : ix0);
+            const int cy = iy0 < 0 ? 0 : (iy0 >= p.H ? p.H - 1 : iy0);
+            const int cx = ix0 < 0 ? 0 : (ix0 >= p.W ? p.W - 1 : ix0);
+            zy |= (iy0 != cy) ? (1u << d) : 0u;
+            zx |= (ix0 != cx) ? (1u << d) : 0u;
+            const int iy = circ ? wy : cy, ix = circ ? wx : cx;
+            const int yv = imgoff + iy * p.W * p.Cin, xv = ix * p.Cin + a_c4 * 4;
+            if (d == 0) { yo0[i] = yv; xo0[i] = xv; } else if (d == 1) { yo1[i] = yv; xo1[i] = xv; } else { yo2[i] = yv; xo2[i] = xv; }
+        }
+        unsigned z = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) z |= (((zy >> (t / 3)) | (zx >> (t % 3))) & 1u) << t;
+        zbits[i] = z;
     }
+    int b_off[B_PT], b_wr[B_PT];
+#pragma unroll
+    for (int i = 0; i < B_PT; ++i) {
+        const int f = tid + i * 256;
+        const int fc = (B_F4 % 256 == 0 || f < B_F4) ? f : 0;
+        const int n = fc / C4, c4 = fc % C4;
+        b_off[i] = n * p.Ktot + c4 * 4;
+        b_wr[i] = n * LDR + c4 * 4;
+    }
+    const float* const wbase = p.w + (int64_t)n0 * p.Ktot;
+
+    // ---- K-step state: (tap, chunk) of the NEXT step to gather, current lane offsets --------------
+    int nx_tap = 0, nx_chunk = 0;                    // wave-uniform
+    int cur[A_PT];
+    unsigned curz = 0;
+    auto set_tap = [&](int tap) {
+        const int dy = tap / p.ks, dx = tap - dy * p.ks;
+        curz = 0;
+#pragma unroll
+        for (int i = 0; i < A_PT; ++i) {
+            const int yo = dy == 0 ? yo0[i] : (dy == 1 ? yo1[i] : yo2[i]);
+            const int xo = dx == 0 ? xo0[i] : (dx == 1 ? xo1[i] : xo2[i]);
+            cur[i] = yo + xo;
+            if (PADZ) curz |= ((zbits[i] >> (dy * 3 + dx)) & 1u) << i;
+        }
+    };
+    set_tap(0);
 
     f32x4 ra[A_PT], rb[B_PT];
-    unsigned ra_zero = 0;            // bit i: tap of pixel i fell into the zero padding
+    unsigned raz = 0;
+    auto gather = [&]() {                            // issue the loads of step (nx_tap, nx_chunk), then advance
+        const float* xs = xb + nx_chunk * KC;                                          // uniform
+        const float* ws = wbase + (nx_tap * p.n_chunks + nx_chunk) * KC;               // uniform
+#pragma unroll
+        for (int i = 0; i < A_PT; ++i) ra[i] = *reinterpret_cast<const f32x4*>(xs + cur[i]);
+#pragma unroll
+        for (int i = 0; i < B_PT; ++i) rb[i] = *reinterpret_cast<const f32x4*>(ws + b_off[i]);
+        raz = curz;
+        if (++nx_chunk == p.n_chunks) {
+            nx_chunk = 0;
+            ++nx_tap;
+            if (nx_tap < p.ks * p.ks) set_tap(nx_tap);
+        }
+    };
+    auto stage = [&](float* As, float* Bs) {         // registers -> LDS (+ Fixup pre-op, zero padding)
+#pragma unroll
+        for (int i = 0; i < A_PT; ++i) {
+            f32x4 v = ra[i];
+            if (PRE != VQAE_PRE_NONE) {
+                v = v + p.pre_a;
+                if (PRE == VQAE_PRE_BIAS_ELU_BIAS) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = elu1(v[e]) + p.pre_b;
+                }
+            }
+            if (PADZ) { if ((raz >> i) & 1u) v = (f32x4)(0.f); }
+            *reinterpret_cast<f32x4*>(As + a_wr[i]) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_PT; ++i)
+            if (B_F4 % 256 == 0 || tid + i * 256 < B_F4) *reinterpret_cast<f32x4*>(Bs + b_wr[i]) = rb[i];
+    };
 
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -187,16 +214,9 @@ void conv_mfma_kernel(const ConvK p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    const int frag_row = lane & 31;
-    const int frag_k = 4 * (lane >> 5);
-
-    conv_load_step<A_PT, B_PT, NT, KC>(p, 0, tid, n0, a_c4, a_oy, a_ox, a_img, ra, rb, ra_zero);
-    conv_store_step<A_PT, B_PT, NT, KC>(p, Abuf0, Bbuf0, tid, a_c4, a_row, ra, rb, ra_zero);
-    __syncthreads();
-
-    auto compute = [&](int buf) {
-        const float* As = Abuf0 + buf * 128 * LDR + (wm * MI * 32 + frag_row) * LDR + frag_k;
-        const float* Bs = Bbuf0 + buf * NT * LDR + (wn * NI * 32 + frag_row) * LDR + frag_k;
+    const float* const a_frag = Abuf0 + (wm * MI * 32 + (lane & 31)) * LDR + 4 * (lane >> 5);
+    const float* const b_frag = Bbuf0 + (wn * NI * 32 + (lane & 31)) * LDR + 4 * (lane >> 5);
+    auto compute = [&](const float* As, const float* Bs) {
 #pragma unroll
         for (int u = 0; u < KC / 8; ++u) {
             f32x4 a[MI], b[NI];
@@ -214,50 +234,77 @@ void conv_mfma_kernel(const ConvK p) {
         }
     };
 
-    // main loop (last step peeled so the body is branch-free: gather s+1 -> MFMAs of s -> LDS store of s+1)
-    const int last = p.n_steps - 1;
-    for (int s = 0; s < last; ++s) {
-        const int buf = s & 1;
-        conv_load_step<A_PT, B_PT, NT, KC>(p, s + 1, tid, n0, a_c4, a_oy, a_ox, a_img, ra, rb, ra_zero);
-        __builtin_amdgcn_sched_barrier(0);      // keep the gather ahead of the MFMAs (hipcc sinks it otherwise)
-        compute(buf);
-        __builtin_amdgcn_sched_barrier(0);
-        conv_store_step<A_PT, B_PT, NT, KC>(p, Abuf0 + (buf ^ 1) * 128 * LDR, Bbuf0 + (buf ^ 1) * NT * LDR, tid,
-                                            a_c4, a_row, ra, rb, ra_zero);
-        __syncthreads();
-    }
-    compute(last & 1);
+    // prologue: step 0 -> buffer 0
+    gather();
+    stage(Abuf0, Bbuf0);
+    __syncthreads();
 
-    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // main loop, unrolled over the two LDS buffers: gather s+1 | MFMAs of s | stage s+1 | barrier
+    int remaining = p.n_steps - 1;                   // steps still to be gathered
+    while (remaining >= 2) {
+        gather();
+        __builtin_amdgcn_sched_barrier(0);
+        compute(a_frag, b_frag);
+        __builtin_amdgcn_sched_barrier(0);
+        stage(Abuf0 + A_BUF, Bbuf0 + B_BUF);
+        __syncthreads();
+        gather();
+        __builtin_amdgcn_sched_barrier(0);
+        compute(a_frag + A_BUF, b_frag + B_BUF);
+        __builtin_amdgcn_sched_barrier(0);
+        stage(Abuf0, Bbuf0);
+        __syncthreads();
+        remaining -= 2;
+    }
+    if (remaining == 1) {
+        gather();
+        __builtin_amdgcn_sched_barrier(0);
+        compute(a_frag, b_frag);
+        __builtin_amdgcn_sched_barrier(0);
+        stage(Abuf0 + A_BUF, Bbuf0 + B_BUF);
+        __syncthreads();
+        compute(a_frag + A_BUF, b_frag + B_BUF);
+    } else {
+        compute(a_frag, b_frag);
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------------
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+    // Output / residual rows of this tile are addressed through buffer descriptors based at row m0 whose
+    // range ends at row M: the hardware drops the stores (and zero-fills the loads) of the M tail.
+    const int rows_valid = (p.M - m0 < 128) ? (p.M - m0) : 128;
+    const unsigned range = (unsigned)rows_valid * (unsigned)p.Cout * 4u;
+    const __amdgpu_buffer_rsrc_t y_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(p.y + (int64_t)m0 * p.Cout, 0, (int)range, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.residual ? p.residual + (int64_t)m0 * p.Cout : p.y), 0, p.residual ? (int)range : 0, 0x00020000);
     const int col = lane & 31;
     const int rhalf = 4 * (lane >> 5);
-    const bool full_tile = (m0 + 128 <= p.M) && (n0 + NT <= p.Cout);     // wave-uniform fast path
+    const int row_bytes = p.Cout * 4;
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-        const int n = n0 + wn * NI * 32 + ni * 32 + col;
-        const bool n_ok = full_tile || n < p.Cout;
-        const float bv = (p.bias_vec && n_ok) ? p.bias_vec[n] : 0.f;
+        const int nl = wn * NI * 32 + ni * 32 + col;
+        const bool n_ok = n0 + nl < p.Cout;
+        const float bv = (p.bias_vec && n_ok) ? p.bias_vec[n0 + nl] : 0.f;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-            const int mb = m0 + wm * MI * 32 + mi * 32 + rhalf;
+            // a column past Cout gets an offset beyond the range -> dropped by the range check
+            const unsigned base = n_ok ? (unsigned)((wm * MI * 32 + mi * 32 + rhalf) * row_bytes + (n0 + nl) * 4) : 0xF0000000u;
             float res[16];
             if (p.residual) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mb + (r & 3) + 8 * (r >> 2);
-                    res[r] = (full_tile || (n_ok && m < p.M)) ? p.residual[(int64_t)m * p.Cout + n] : 0.f;
-                }
+                for (int r = 0; r < 16; ++r)
+                    res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, base + ((r & 3) + 8 * (r >> 2)) * row_bytes, 0, 0));
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = mb + (r & 3) + 8 * (r >> 2);
                 float t = acc[mi][ni][r];
                 if (p.has_scale) { t = t * p.scale; t = t + p.bias_s; }
                 else if (p.has_bias_s) { t = t + p.bias_s; }
                 if (p.bias_vec) t = t + bv;
                 if (p.residual) t = t + res[r];
                 if (p.has_act) t = elu1(t + p.act_a) + p.act_b;
-                if (full_tile || (n_ok && m < p.M)) p.y[(int64_t)m * p.Cout + n] = t;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), y_rsrc, base + ((r & 3) + 8 * (r >> 2)) * row_bytes, 0, 0);
             }
         }
     }
@@ -273,31 +320,48 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int cout, int ci
     out[i] = (n < cout) ? w[((int64_t)n * cin + ci) * ks * ks + tap] : 0.f;
 }
 
-template <int NT, int KC>
+template <int NT, int KC, int PRE, bool PADZ>
 int launch(const ConvK& k, hipStream_t stream) {
     const int npad = (int)vqae::round_up(k.Cout, 32);
     dim3 grid((unsigned)vqae::ceil_div(k.M, 128), (unsigned)vqae::ceil_div(npad, NT));
     constexpr int lds_bytes = 2 * (128 + NT) * (KC + 4) * (int)sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)conv_mfma_kernel<NT, KC>,
+        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)conv_mfma_kernel<NT, KC, PRE, PADZ>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         attr_set = true;
     }
     const int cls = (NT == 128 && KC == 32 && k.Cin >= 128) ? (k.ks == 3 ? vqae::PROF_CONV3X3_TRUNK : (k.ks == 1 ? vqae::PROF_CONV1X1_TRUNK : 0)) : 0;
     vqae::ProfScope prof(cls, stream);
-    conv_mfma_kernel<NT, KC><<<grid, 256, lds_bytes, stream>>>(k);
+    conv_mfma_kernel<NT, KC, PRE, PADZ><<<grid, 256, lds_bytes, stream>>>(k);
     prof.done();
     VQAE_LAUNCH_CHECK();
     return VQAE_OK;
 }
 
+template <int NT, int KC>
+int launch_pre(const ConvK& k, hipStream_t stream) {
+    const bool padz = k.pad > 0 && k.pad_mode == VQAE_PAD_ZEROS;
+    if (padz) {       // zero padding is only used by tests / generic callers: one (slower) variant
+        switch (k.pre_mode) {
+            case VQAE_PRE_NONE: return launch<NT, KC, VQAE_PRE_NONE, true>(k, stream);
+            case VQAE_PRE_BIAS: return launch<NT, KC, VQAE_PRE_BIAS, true>(k, stream);
+            default: return launch<NT, KC, VQAE_PRE_BIAS_ELU_BIAS, true>(k, stream);
+        }
+    }
+    switch (k.pre_mode) {
+        case VQAE_PRE_NONE: return launch<NT, KC, VQAE_PRE_NONE, false>(k, stream);
+        case VQAE_PRE_BIAS: return launch<NT, KC, VQAE_PRE_BIAS, false>(k, stream);
+        default: return launch<NT, KC, VQAE_PRE_BIAS_ELU_BIAS, false>(k, stream);
+    }
+}
+
 template <int NT>
 int launch_kc(const ConvK& k, int kc, hipStream_t stream) {
     switch (kc) {
-        case 32: return launch<NT, 32>(k, stream);
-        case 16: return launch<NT, 16>(k, stream);
-        default: return launch<NT, 8>(k, stream);
+        case 32: return launch_pre<NT, 32>(k, stream);
+        case 16: return launch_pre<NT, 16>(k, stream);
+        default: return launch_pre<NT, 8>(k, stream);
     }
 }
 
@@ -337,6 +401,11 @@ extern "C" int vqae_conv2d_f32(const vqae_conv_args* a, const float* x, const fl
         VQAE_REQUIRE(a->pad <= a->in_h && a->pad <= a->in_w, VQAE_ERR_INVALID, "conv2d: circular pad larger than input");
     const int64_t M = (int64_t)a->batch * Ho * Wo;
     VQAE_REQUIRE(M < (1ll << 31) - 256, VQAE_ERR_UNSUPPORTED, "conv2d: too many output pixels (%lld)", (long long)M);
+    VQAE_REQUIRE(a->pre_mode >= VQAE_PRE_NONE && a->pre_mode <= VQAE_PRE_BIAS_ELU_BIAS, VQAE_ERR_INVALID, "conv2d: pre_mode %d", a->pre_mode);
+    // lane offsets are 32-bit and relative to the first image of a 128-pixel tile (which spans at most
+    // 128 / (Ho*Wo) + 2 images)
+    VQAE_REQUIRE(((int64_t)128 / (Ho * Wo) + 3) * a->in_h * a->in_w * a->cin < (1ll << 30), VQAE_ERR_UNSUPPORTED,
+                 "conv2d: image too large for 32-bit tile-relative offsets");
     if (M == 0) return VQAE_OK;
 
     ConvK k;

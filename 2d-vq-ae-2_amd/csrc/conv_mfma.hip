@@ -181,6 +181,8 @@ void conv_mfma_kernel(const ConvK p) {
 #pragma unroll
         for (int i = 0; i < B_PT; ++i) rb[i] = *reinterpret_cast<const f32x4*>(ws + b_off[i]);
         raz = curz;
+    };
+    auto advance = [&]() {                           // move (nx_tap, nx_chunk) to the following step
         if (++nx_chunk == p.n_chunks) {
             nx_chunk = 0;
             ++nx_tap;
@@ -234,34 +236,49 @@ void conv_mfma_kernel(const ConvK p) {
         }
     };
 
+    // One K-step as a single scheduling region: the gather's loads are issued between the first MFMAs,
+    // the LDS stores of the gathered tile between the last ones, so the matrix pipe (64 cycles per
+    // 32x32x2 MFMA) never drains while this wave issues memory instructions.
+    constexpr int N_MFMA = MI * NI * (KC / 2);       // MFMAs per wave per step
+    constexpr int N_LD = A_PT + B_PT;                // global loads / LDS stores per thread per step
+    auto step = [&](const float* As, const float* Bs, float* Asn, float* Bsn) {
+        gather();
+        compute(As, Bs);
+        stage(Asn, Bsn);
+        if (N_MFMA >= 4 * N_LD) {
+#pragma unroll
+            for (int i = 0; i < N_LD; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // 1 VMEM read
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, N_MFMA - 3 * N_LD, 0);
+#pragma unroll
+            for (int i = 0; i < N_LD; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);     // 1 DS write
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);     // 2 MFMA
+            }
+        }
+    };
+
     // prologue: step 0 -> buffer 0
     gather();
+    advance();
     stage(Abuf0, Bbuf0);
     __syncthreads();
 
-    // main loop, unrolled over the two LDS buffers: gather s+1 | MFMAs of s | stage s+1 | barrier
+    // main loop, unrolled over the two LDS buffers
     int remaining = p.n_steps - 1;                   // steps still to be gathered
     while (remaining >= 2) {
-        gather();
-        __builtin_amdgcn_sched_barrier(0);
-        compute(a_frag, b_frag);
-        __builtin_amdgcn_sched_barrier(0);
-        stage(Abuf0 + A_BUF, Bbuf0 + B_BUF);
+        step(a_frag, b_frag, Abuf0 + A_BUF, Bbuf0 + B_BUF);
         __syncthreads();
-        gather();
-        __builtin_amdgcn_sched_barrier(0);
-        compute(a_frag + A_BUF, b_frag + B_BUF);
-        __builtin_amdgcn_sched_barrier(0);
-        stage(Abuf0, Bbuf0);
+        advance();
+        step(a_frag + A_BUF, b_frag + B_BUF, Abuf0, Bbuf0);
         __syncthreads();
+        advance();
         remaining -= 2;
     }
     if (remaining == 1) {
-        gather();
-        __builtin_amdgcn_sched_barrier(0);
-        compute(a_frag, b_frag);
-        __builtin_amdgcn_sched_barrier(0);
-        stage(Abuf0 + A_BUF, Bbuf0 + B_BUF);
+        step(a_frag, b_frag, Abuf0 + A_BUF, Bbuf0 + B_BUF);
         __syncthreads();
         compute(a_frag + A_BUF, b_frag + B_BUF);
     } else {

@@ -54,6 +54,9 @@ SYMBOLS = {
     "vqae_conv_packed_floats": (c_size_t, [c_int, c_int, c_int]),
     "vqae_conv_pack_weight_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vqae_conv2d_f32": (c_int, [POINTER(ConvArgs), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vqae_fixup_same_supported": (c_int, [c_int, c_int, c_int]),
+    "vqae_fixup_same_block_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                          POINTER(c_float), c_void_p]),
     "vqae_conv3x3_direct_f32": (c_int, [c_void_p, c_void_p, POINTER(c_float), POINTER(c_float), c_void_p, c_void_p,
                                         c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vqae_bicubic_up2_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),

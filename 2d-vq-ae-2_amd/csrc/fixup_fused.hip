@@ -1,0 +1,261 @@
+// Fused Fixup "same" block for the high-resolution, small-channel levels (C = 16 / 32):
+//   y = conv3(ELU(conv2(ELU(conv1(ELU(x+b1a)+b1b)+b2a)+b2b)+b3a)+b3b)*scale + b4 + x
+// (reference vq_ae/layers/conv_block.py:196-216, mode 'same': 1x1 -> 3x3 circular -> 1x1) in ONE kernel.
+//
+// Unfused, these levels are HBM-bound: the activation tensors are 8x larger than at the 32x32 trunk
+// (C*H*W = 1 M floats per patch) and a block makes 7 passes over them.  Here a workgroup owns a
+// TH x 32 pixel tile of one image: it computes conv1 on the (TH+2) x 34 halo straight from global
+// memory (operand fragments loaded in MFMA layout, Fixup pre-op applied in registers), keeps t1 in LDS,
+// runs the 9 taps of the 3x3 from that LDS tile (no re-staging), writes t2 over t1, runs conv3 and adds
+// the residual: algorithmic HBM traffic = one read + one write of the activation (+ halo rows).
+// All three weight matrices stay resident in LDS ([n][k] rows, +4 float pad: conflict-free
+// ds_read_b128 fragments); workgroups are persistent and walk tiles in an XCD-contiguous order.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct FusedP {
+    const float* __restrict__ x;
+    float* __restrict__ y;
+    const float* __restrict__ w1;   // packed [>=32][C]
+    const float* __restrict__ w2;   // packed [>=32][9C]
+    const float* __restrict__ w3;   // packed [>=32][C]
+    int B, H, W;
+    int tiles_x, tiles_y, n_tiles;
+    float b1a, b1b, b2a, b2b, b3a, b3b, b4, scale;
+};
+
+__device__ __forceinline__ float elu1f(float v) {      // see conv_mfma.hip
+    const float x = fmaxf(fminf(v, 0.f), -88.f);
+    const float k = __builtin_rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(k, -0.693145751953125f, x);
+    r = __builtin_fmaf(k, -1.42860682030941723e-06f, r);
+    float p = 1.98412698e-04f;
+    p = __builtin_fmaf(p, r, 1.38888889e-03f);
+    p = __builtin_fmaf(p, r, 8.33333333e-03f);
+    p = __builtin_fmaf(p, r, 4.16666667e-02f);
+    p = __builtin_fmaf(p, r, 1.66666667e-01f);
+    p = __builtin_fmaf(p, r, 0.5f);
+    const float em = __builtin_fmaf(p * r, r, r);
+    const float sc = __builtin_ldexpf(1.0f, (int)k);
+    const float e = __builtin_fmaf(sc, em, sc - 1.0f);
+    return v > 0.f ? v : e;
+}
+
+template <int C, int TH>
+struct FusedCfg {
+    static constexpr int LDT = C + 4;                  // t1 / t2 row stride (floats)
+    static constexpr int LDW2 = 9 * C + 4;             // W2 row stride
+    static constexpr int HP = (TH + 2) * 34;           // halo pixels
+    static constexpr int HPP = (HP + 31) / 32 * 32;
+    static constexpr int G1 = HPP / 32;                // 32-pixel groups of the halo (conv1 M tiles)
+    static constexpr int GPW = (G1 + 3) / 4;           // per wave
+    static constexpr int MPW = TH / 4;                 // output image rows (M tiles) per wave
+    static constexpr int LDS_FLOATS = 2 * 32 * LDT + 32 * LDW2 + HPP * LDT;
+};
+
+template <int C, int TH>
+__global__ __launch_bounds__(256, (C == 16 ? 3 : 2))
+void fixup_same_small_kernel(const FusedP p) {
+    using K = FusedCfg<C, TH>;
+    constexpr int LDT = K::LDT, LDW2 = K::LDW2, HP = K::HP, G1 = K::G1, GPW = K::GPW, MPW = K::MPW;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const W1s = lds;
+    float* const W3s = W1s + 32 * LDT;
+    float* const W2s = W3s + 32 * LDT;
+    float* const T1 = W2s + 32 * LDW2;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, h = lane >> 5;
+
+    // weights -> LDS, once per (persistent) workgroup
+    for (int i = tid; i < 32 * (C / 4); i += 256) {
+        const int n = i / (C / 4), c4 = i % (C / 4);
+        *reinterpret_cast<f32x4*>(W1s + n * LDT + 4 * c4) = *reinterpret_cast<const f32x4*>(p.w1 + n * C + 4 * c4);
+        *reinterpret_cast<f32x4*>(W3s + n * LDT + 4 * c4) = *reinterpret_cast<const f32x4*>(p.w3 + n * C + 4 * c4);
+    }
+    for (int i = tid; i < 32 * (9 * C / 4); i += 256) {
+        const int n = i / (9 * C / 4), c4 = i % (9 * C / 4);
+        *reinterpret_cast<f32x4*>(W2s + n * LDW2 + 4 * c4) = *reinterpret_cast<const f32x4*>(p.w2 + n * 9 * C + 4 * c4);
+    }
+    __syncthreads();
+
+    // XCD-contiguous tile ranges: blocks b, b+8, ... share an XCD (L2); give each XCD a contiguous run of
+    // tiles so the halo rows of neighbouring tiles hit in one L2 (speed only).
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3, per_xcd_wg = (nwg + 7 - xcd) >> 3;
+    const int q = p.n_tiles >> 3, rr = p.n_tiles & 7;
+    const int xcd_lo = xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q;
+    const int xcd_n = q + (xcd < rr ? 1 : 0);
+
+    const float* const w1f = W1s + li * LDT + 4 * h;
+    const float* const w3f = W3s + li * LDT + 4 * h;
+    const float* const w2f = W2s + li * LDW2 + 4 * h;
+
+    for (int t = slot; t < xcd_n; t += per_xcd_wg) {
+        const int tile = xcd_lo + t;
+        const int txi = tile % p.tiles_x;
+        const int tyi = (tile / p.tiles_x) % p.tiles_y;
+        const int b = tile / (p.tiles_x * p.tiles_y);
+        const int ty0 = tyi * TH, tx0 = txi * 32;
+        const float* const xim = p.x + (int64_t)b * p.H * p.W * C;
+
+        // ---- P1: t1 = ELU(conv1(ELU(x+b1a)+b1b) + b2a) + b2b on the halo ---------------------------
+#pragma unroll
+        for (int gi = 0; gi < GPW; ++gi) {
+            const int g = wave + 4 * gi;
+            if (g < G1) {
+                int hp = 32 * g + li;
+                hp = hp < HP ? hp : HP - 1;
+                const int hy = hp / 34, hx = hp - 34 * hy;
+                int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
+                iy = iy < 0 ? iy + p.H : (iy >= p.H ? iy - p.H : iy);
+                ix = ix < 0 ? ix + p.W : (ix >= p.W ? ix - p.W : ix);
+                const float* src = xim + ((int64_t)iy * p.W + ix) * C + 4 * h;
+                f32x4 a[C / 8];
+#pragma unroll
+                for (int u = 0; u < C / 8; ++u) a[u] = *reinterpret_cast<const f32x4*>(src + 8 * u);
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int u = 0; u < C / 8; ++u) {
+                    f32x4 v = a[u] + p.b1a;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = elu1f(v[e]) + p.b1b;
+                    const f32x4 bw = *reinterpret_cast<const f32x4*>(w1f + 8 * u);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[r], bw[r], acc, 0, 0, 0);
+                }
+                if (li < C) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                        T1[(32 * g + row) * LDT + li] = elu1f(acc[r] + p.b2a) + p.b2b;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- P2: 3x3 circular conv straight from the LDS halo tile --------------------------------
+        f32x16 acc2[MPW];
+#pragma unroll
+        for (int mt = 0; mt < MPW; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[mt][r] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+            for (int u = 0; u < C / 8; ++u) {
+                const f32x4 bw = *reinterpret_cast<const f32x4*>(w2f + tap * C + 8 * u);
+#pragma unroll
+                for (int mt = 0; mt < MPW; ++mt) {
+                    const int ry = wave + 4 * mt;
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(T1 + ((ry + dy) * 34 + li + dx) * LDT + 8 * u + 4 * h);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[r], bw[r], acc2[mt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                               // every wave is done reading t1
+        if (li < C) {
+#pragma unroll
+            for (int mt = 0; mt < MPW; ++mt) {
+                const int ry = wave + 4 * mt;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    T1[(ry * 32 + row) * LDT + li] = elu1f(acc2[mt][r] + p.b3a) + p.b3b;   // t2 over t1
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- P3: conv3 (1x1) + scale/bias4 + residual ----------------------------------------------
+#pragma unroll
+        for (int mt = 0; mt < MPW; ++mt) {
+            const int ry = wave + 4 * mt;
+            f32x16 acc3;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc3[r] = 0.f;
+#pragma unroll
+            for (int u = 0; u < C / 8; ++u) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(T1 + (ry * 32 + li) * LDT + 8 * u + 4 * h);
+                const f32x4 bw = *reinterpret_cast<const f32x4*>(w3f + 8 * u);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[r], bw[r], acc3, 0, 0, 0);
+            }
+            if (li < C) {
+                const int64_t rowbase = (((int64_t)b * p.H + ty0 + ry) * p.W + tx0) * C + li;
+                float res[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) res[r] = p.x[rowbase + ((r & 3) + 8 * (r >> 2) + 4 * h) * C];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float tv = acc3[r] * p.scale;
+                    tv = tv + p.b4;
+                    tv = tv + res[r];
+                    p.y[rowbase + ((r & 3) + 8 * (r >> 2) + 4 * h) * C] = tv;
+                }
+            }
+        }
+        __syncthreads();                               // t2 is dead: the next tile may overwrite the LDS tile
+    }
+}
+
+template <int C, int TH>
+int launch_fused(FusedP& p, hipStream_t stream) {
+    using K = FusedCfg<C, TH>;
+    constexpr int lds_bytes = K::LDS_FLOATS * (int)sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)fixup_same_small_kernel<C, TH>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        attr_set = true;
+    }
+    p.tiles_x = p.W / 32;
+    p.tiles_y = p.H / TH;
+    p.n_tiles = p.B * p.tiles_x * p.tiles_y;
+    const int per_cu = (C == 16 ? 3 : 2);
+    int grid = 256 * per_cu;
+    if (grid > p.n_tiles) grid = p.n_tiles;
+    fixup_same_small_kernel<C, TH><<<grid, 256, lds_bytes, stream>>>(p);
+    VQAE_LAUNCH_CHECK();
+    return VQAE_OK;
+}
+
+}  // namespace
+
+extern "C" int vqae_fixup_same_supported(int c, int h, int w) {
+    if (w % 32 != 0) return 0;
+    if (c == 16) return h % 8 == 0;
+    if (c == 32) return h % 4 == 0;
+    return 0;
+}
+
+extern "C" int vqae_fixup_same_block_f32(const float* x, float* y, const float* w1_packed, const float* w2_packed,
+                                         const float* w3_packed, int batch, int h, int w, int c,
+                                         const float* scalars8, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VQAE_REQUIRE(scalars8, VQAE_ERR_INVALID, "fixup_same_block: null scalars");
+    if (batch == 0) return VQAE_OK;
+    VQAE_REQUIRE(x && y && w1_packed && w2_packed && w3_packed, VQAE_ERR_INVALID, "fixup_same_block: null pointer");
+    VQAE_REQUIRE(x != y, VQAE_ERR_INVALID, "fixup_same_block: in-place is not supported (halo reads)");
+    VQAE_REQUIRE(vqae_fixup_same_supported(c, h, w), VQAE_ERR_UNSUPPORTED,
+                 "fixup_same_block: unsupported shape C=%d H=%d W=%d", c, h, w);
+    FusedP p;
+    p.x = x; p.y = y; p.w1 = w1_packed; p.w2 = w2_packed; p.w3 = w3_packed;
+    p.B = batch; p.H = h; p.W = w;
+    p.b1a = scalars8[0]; p.b1b = scalars8[1]; p.b2a = scalars8[2]; p.b2b = scalars8[3];
+    p.b3a = scalars8[4]; p.b3b = scalars8[5]; p.b4 = scalars8[6]; p.scale = scalars8[7];
+    if (c == 16) return launch_fused<16, 8>(p, stream);
+    return launch_fused<32, 4>(p, stream);
+}

@@ -201,6 +201,13 @@ struct ConvCall {
 int run_block(vqae_handle* h, const Block& b, int B, int& H, int& W, hipStream_t st) {
     float *X = h->buf[0], *P = h->buf[1], *Q = h->buf[2], *R = h->buf[3];
     int rc;
+    if (b.mode == MODE_SAME && b.cin == b.cout && vqae_fixup_same_supported(b.cin, H, W)) {
+        // high-resolution levels: the whole block in one launch (csrc/fixup_fused.hip), X -> P, swap
+        const float sc[8] = {b.b1a, b.b1b, b.b2a, b.b2b, b.b3a, b.b3b, b.b4, b.scale};
+        if ((rc = vqae_fixup_same_block_f32(X, P, b.w1, b.w2, b.w3, B, H, W, b.cin, sc, st))) return rc;
+        std::swap(h->buf[0], h->buf[1]);
+        return VQAE_OK;
+    }
     if (b.mode == MODE_SAME) {
         ConvCall c1(B, H, W, b.cin, b.br, 1, 1, 0, VQAE_PAD_NONE);
         c1.pre(VQAE_PRE_BIAS_ELU_BIAS, b.b1a, b.b1b).act(b.b2a, b.b2b);

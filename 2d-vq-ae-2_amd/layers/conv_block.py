@@ -110,6 +110,12 @@ class PreActFixupResBlock(nn.Module):
         """conv_block.py:196-216 on an NHWC tensor (the block's native layout)."""
         f = lambda p: float(p.detach())
         br = self.branch_channels
+        if (self.mode == "same" and br == self.in_channels
+                and ops.fixup_same_supported(self.in_channels, x.shape[1], x.shape[2])):
+            return ops.fixup_same_block(x, self.branch_conv1.packed(), self.branch_conv2.packed(),
+                                        self.branch_conv3.packed(),
+                                        [f(self.bias1a), f(self.bias1b), f(self.bias2a), f(self.bias2b),
+                                         f(self.bias3a), f(self.bias3b), f(self.bias4), f(self.scale)])
         t = ops.conv2d(x, self.branch_conv1.packed(), br, 1, pre=(f(self.bias1a), f(self.bias1b)),
                        act=(f(self.bias2a), f(self.bias2b)))
         if self.mode == "same":

@@ -90,6 +90,21 @@ def conv2d(x, w_packed, cout, ksize, stride=1, pad=0, pad_mode=L.PAD_NONE, pre=N
     return out
 
 
+def fixup_same_supported(c, h, w):
+    return bool(L.lib().vqae_fixup_same_supported(c, h, w))
+
+
+def fixup_same_block(x, w1p, w2p, w3p, scalars8):
+    """Whole 'same' Fixup block in one launch (x NHWC [B,H,W,C]); scalars8 = (b1a,b1b,b2a,b2b,b3a,b3b,b4,scale)."""
+    _need_gpu(x, w1p, w2p, w3p)
+    x = x.contiguous()
+    B, H, W, C = x.shape
+    y = torch.empty_like(x)
+    sc = (ctypes.c_float * 8)(*[float(v) for v in scalars8])
+    L.check(L.lib().vqae_fixup_same_block_f32(_p(x), _p(y), _p(w1p), _p(w2p), _p(w3p), B, H, W, C, sc, _stream()))
+    return y
+
+
 def conv3x3_direct(x, w, bias, x_u8=None, mean255=None, inv_std255=None):
     """Stem conv (3x3, zero pad, bias); x NHWC fp32 or x_u8 NHWC uint8 (normalised on device)."""
     src = x if x_u8 is None else x_u8

@@ -124,6 +124,16 @@ typedef struct vqae_conv_args {
 int vqae_conv2d_f32(const vqae_conv_args* a, const float* x_dev, const float* w_packed_dev,
                     const float* bias_vec_dev, const float* residual_dev, float* y_dev, void* stream);
 
+/* One whole PreActFixupResBlock.forward, mode 'same' (conv_block.py:196-216: 1x1 -> 3x3 circular -> 1x1,
+ * in_channels == out_channels == c) in a single launch, for the HBM-bound high-resolution levels.
+ * x_dev, y_dev [B][H][W][c] (y != x: neighbouring tiles read halo rows of x); w*_packed_dev from
+ * vqae_conv_pack_weight_f32; scalars8 (host) = {bias1a, bias1b, bias2a, bias2b, bias3a, bias3b, bias4, scale}.
+ * vqae_fixup_same_supported() tells whether a (c, h, w) has a fused kernel (c in {16, 32}, w % 32 == 0). */
+int vqae_fixup_same_supported(int c, int h, int w);
+int vqae_fixup_same_block_f32(const float* x_dev, float* y_dev, const float* w1_packed_dev, const float* w2_packed_dev,
+                              const float* w3_packed_dev, int batch, int h, int w, int c, const float* scalars8,
+                              void* stream);
+
 /* Direct (VALU) 3x3 / stride 1 / zero-pad conv with per-channel bias for tiny channel counts:
  * the stems `in_stem` (3 -> C0, model.py:198) and `out_stem` (C0 -> 3, model.py:291).
  * w_oihw_dev is the PyTorch-layout weight [cout][cin][3][3]; cin, cout <= 64.

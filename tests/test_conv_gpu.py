@@ -150,3 +150,32 @@ def test_stitch_tiles_matches_driver_fixture(amd, oracle):
         amd.ops.stitch_tiles(torch.from_numpy(tiles[sel]).cuda(), torch.from_numpy(meta[sel][:, 1:]).cuda(), grid)
         out = oracle.cast_to_lowest_dtype(grid.cpu().numpy())
         assert out.dtype == g["grid:" + name].dtype and np.array_equal(out, g["grid:" + name])
+
+
+@pytest.mark.parametrize("C,H,W,B", [(16, 16, 32, 2), (16, 8, 64, 3), (32, 8, 32, 2), (32, 12, 64, 1), (16, 256, 256, 1)])
+def test_fused_same_block_matches_oracle(amd, oracle, C, H, W, B):
+    """Fused 1x1 -> 3x3 circular -> 1x1 Fixup block (one launch) vs the CPU oracle's fixup_block."""
+    assert amd.ops.fixup_same_supported(C, H, W)
+    g = torch.Generator().manual_seed(C + H + W)
+    p = {}
+    for n in ("bias1a", "bias1b", "bias2a", "bias2b", "bias3a", "bias3b", "bias4"):
+        p["blk." + n] = (torch.rand(1, generator=g) - 0.5) * 0.4
+    p["blk.scale"] = torch.rand(1, generator=g) + 0.5
+    p["blk.branch_conv1.weight"] = torch.randn(C, C, 1, 1, generator=g) / C ** 0.5
+    p["blk.branch_conv2.weight"] = torch.randn(C, C, 3, 3, generator=g) / (9 * C) ** 0.5
+    p["blk.branch_conv3.weight"] = torch.randn(C, C, 1, 1, generator=g) / C ** 0.5
+    x = torch.randn(B, C, H, W, generator=g)
+    ref = oracle.fixup_block(x, p, "blk", "same")
+    packed = [amd.ops.pack_conv_weight(p[f"blk.branch_conv{i}.weight"].cuda()) for i in (1, 2, 3)]
+    sc = [float(p["blk." + n]) for n in ("bias1a", "bias1b", "bias2a", "bias2b", "bias3a", "bias3b", "bias4", "scale")]
+    y = amd.ops.fixup_same_block(nhwc(x).cuda(), *packed, sc)
+    torch.cuda.synchronize()
+    close(nchw(y.cpu()), ref)
+
+
+def test_fused_same_block_unsupported_shapes(amd):
+    assert not amd.ops.fixup_same_supported(128, 32, 32)       # trunk: stays on the 3-launch MFMA path
+    assert not amd.ops.fixup_same_supported(16, 8, 16)         # W % 32 != 0
+    with pytest.raises(NotImplementedError):
+        amd.ops.fixup_same_block(torch.zeros(1, 8, 16, 16).cuda(), torch.zeros(8).cuda(), torch.zeros(8).cuda(),
+                                 torch.zeros(8).cuda(), [0] * 8)

@@ -219,20 +219,29 @@ void conv_mfma_kernel(const ConvK p) {
     const float* const a_frag = Abuf0 + (wm * MI * 32 + (lane & 31)) * LDR + 4 * (lane >> 5);
     const float* const b_frag = Bbuf0 + (wn * NI * 32 + (lane & 31)) * LDR + 4 * (lane >> 5);
     auto compute = [&](const float* As, const float* Bs) {
+        // fragment reads are software-pipelined one 8-deep k-slice ahead of the MFMAs that use them
+        f32x4 a[2][MI], b[2][NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) a[0][mi] = *reinterpret_cast<const f32x4*>(As + mi * 32 * LDR);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) b[0][ni] = *reinterpret_cast<const f32x4*>(Bs + ni * 32 * LDR);
 #pragma unroll
         for (int u = 0; u < KC / 8; ++u) {
-            f32x4 a[MI], b[NI];
+            if (u + 1 < KC / 8) {
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(As + mi * 32 * LDR + 8 * u);
+                for (int mi = 0; mi < MI; ++mi)
+                    a[(u + 1) & 1][mi] = *reinterpret_cast<const f32x4*>(As + mi * 32 * LDR + 8 * (u + 1));
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(Bs + ni * 32 * LDR + 8 * u);
+                for (int ni = 0; ni < NI; ++ni)
+                    b[(u + 1) & 1][ni] = *reinterpret_cast<const f32x4*>(Bs + ni * 32 * LDR + 8 * (u + 1));
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][r], b[ni][r], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u & 1][mi][r], b[u & 1][ni][r], acc[mi][ni], 0, 0, 0);
         }
     };
 

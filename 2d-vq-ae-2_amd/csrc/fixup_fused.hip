@@ -1,4 +1,4 @@
-// Fused Fixup "same" block for the high-resolution, small-channel levels (C = 16 / 32):
+// Fused Fixup "same" block for the high-resolution, small-channel levels (C = 8 / 16 / 32):
 //   y = conv3(ELU(conv2(ELU(conv1(ELU(x+b1a)+b1b)+b2a)+b2b)+b3a)+b3b)*scale + b4 + x
 // (reference vq_ae/layers/conv_block.py:196-216, mode 'same': 1x1 -> 3x3 circular -> 1x1) in ONE kernel.
 //
@@ -58,7 +58,7 @@ struct FusedCfg {
 };
 
 template <int C, int TH>
-__global__ __launch_bounds__(256, (C == 16 ? 3 : 2))
+__global__ __launch_bounds__(256, (C <= 16 ? 3 : 2))
 void fixup_same_small_kernel(const FusedP p) {
     using K = FusedCfg<C, TH>;
     constexpr int LDT = K::LDT, LDW2 = K::LDW2, HP = K::HP, G1 = K::G1, GPW = K::GPW, MPW = K::MPW;
@@ -224,7 +224,7 @@ int launch_fused(FusedP& p, hipStream_t stream) {
     p.tiles_x = p.W / 32;
     p.tiles_y = p.H / TH;
     p.n_tiles = p.B * p.tiles_x * p.tiles_y;
-    const int per_cu = (C == 16 ? 3 : 2);
+    const int per_cu = (C <= 16 ? 3 : 2);
     int grid = 256 * per_cu;
     if (grid > p.n_tiles) grid = p.n_tiles;
     fixup_same_small_kernel<C, TH><<<grid, 256, lds_bytes, stream>>>(p);
@@ -236,7 +236,7 @@ int launch_fused(FusedP& p, hipStream_t stream) {
 
 extern "C" int vqae_fixup_same_supported(int c, int h, int w) {
     if (w % 32 != 0) return 0;
-    if (c == 16) return h % 8 == 0;
+    if (c == 8 || c == 16) return h % 8 == 0;
     if (c == 32) return h % 4 == 0;
     return 0;
 }
@@ -256,6 +256,7 @@ extern "C" int vqae_fixup_same_block_f32(const float* x, float* y, const float* 
     p.B = batch; p.H = h; p.W = w;
     p.b1a = scalars8[0]; p.b1b = scalars8[1]; p.b2a = scalars8[2]; p.b2b = scalars8[3];
     p.b3a = scalars8[4]; p.b3b = scalars8[5]; p.b4 = scalars8[6]; p.scale = scalars8[7];
+    if (c == 8) return launch_fused<8, 8>(p, stream);
     if (c == 16) return launch_fused<16, 8>(p, stream);
     return launch_fused<32, 4>(p, stream);
 }

@@ -128,7 +128,7 @@ int vqae_conv2d_f32(const vqae_conv_args* a, const float* x_dev, const float* w_
  * in_channels == out_channels == c) in a single launch, for the HBM-bound high-resolution levels.
  * x_dev, y_dev [B][H][W][c] (y != x: neighbouring tiles read halo rows of x); w*_packed_dev from
  * vqae_conv_pack_weight_f32; scalars8 (host) = {bias1a, bias1b, bias2a, bias2b, bias3a, bias3b, bias4, scale}.
- * vqae_fixup_same_supported() tells whether a (c, h, w) has a fused kernel (c in {16, 32}, w % 32 == 0). */
+ * vqae_fixup_same_supported() tells whether a (c, h, w) has a fused kernel (c in {8, 16, 32}, w % 32 == 0). */
 int vqae_fixup_same_supported(int c, int h, int w);
 int vqae_fixup_same_block_f32(const float* x_dev, float* y_dev, const float* w1_packed_dev, const float* w2_packed_dev,
                               const float* w3_packed_dev, int batch, int h, int w, int c, const float* scalars8,

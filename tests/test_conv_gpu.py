@@ -152,7 +152,7 @@ def test_stitch_tiles_matches_driver_fixture(amd, oracle):
         assert out.dtype == g["grid:" + name].dtype and np.array_equal(out, g["grid:" + name])
 
 
-@pytest.mark.parametrize("C,H,W,B", [(16, 16, 32, 2), (16, 8, 64, 3), (32, 8, 32, 2), (32, 12, 64, 1), (16, 256, 256, 1)])
+@pytest.mark.parametrize("C,H,W,B", [(16, 16, 32, 2), (16, 8, 64, 3), (32, 8, 32, 2), (32, 12, 64, 1), (16, 256, 256, 1), (8, 16, 64, 2), (8, 512, 512, 1)])
 def test_fused_same_block_matches_oracle(amd, oracle, C, H, W, B):
     """Fused 1x1 -> 3x3 circular -> 1x1 Fixup block (one launch) vs the CPU oracle's fixup_block."""
     assert amd.ops.fixup_same_supported(C, H, W)

@@ -80,7 +80,7 @@ SYMBOLS = {
                              c_void_p]),
     "vqae_flops_per_patch": (c_double, [c_void_p, c_int, c_int, c_int, c_int]),
     "vqae_prof_begin": (c_int, [c_int, c_int]),
-    "vqae_prof_end": (c_int, [POINTER(c_double), POINTER(c_int)]),
+    "vqae_prof_end": (c_int, [POINTER(c_double), POINTER(c_int), POINTER(c_double)]),
 }
 
 _lib = None

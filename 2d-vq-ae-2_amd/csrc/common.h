@@ -42,15 +42,19 @@ struct ProfState {
     int used = 0;
     int cap = 0;
     hipEvent_t* ev = nullptr;
+    double work = 0.0;            // algorithmic flops (or ops) of the timed launches
 };
 ProfState& prof_state();
 struct ProfScope {
     bool on;
     hipStream_t st;
-    ProfScope(int cls, hipStream_t stream) : st(stream) {
+    ProfScope(int cls, hipStream_t stream, double work = 0.0) : st(stream) {
         ProfState& p = prof_state();
         on = cls != 0 && p.cls == cls && p.used + 2 <= p.cap;
-        if (on) (void)hipEventRecord(p.ev[p.used], st);
+        if (on) {
+            p.work += work;
+            (void)hipEventRecord(p.ev[p.used], st);
+        }
     }
     void done() {
         if (!on) return;

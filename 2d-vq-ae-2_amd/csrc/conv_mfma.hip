@@ -37,6 +37,11 @@ struct ConvK {
     float pre_a, pre_b;
     int has_scale, has_bias_s, has_act;
     float scale, bias_s, act_a, act_b;
+    // fused tail (trunk, C = 128): conv3 of this block [+ conv1 of the next block], see TAIL below
+    const float* __restrict__ w3;        // packed [128][128]
+    const float* __restrict__ w1n;       // packed [128][128] of the NEXT block's conv1 (TAIL == 2)
+    float* y2;                           // [M][128]: next block's t1 (TAIL == 2)
+    float t_scale, t_b4, n_b1a, n_b1b, n_b2a, n_b2b;
 };
 
 // ELU(alpha = 1) = v > 0 ? v : expm1(v), branch-free so the Fixup pre-op / epilogue can be scheduled
@@ -71,7 +76,13 @@ __device__ __forceinline__ float elu1(float v) {
 //     base VGPR + immediate;
 //   * the epilogue addresses through buffer descriptors (hardware range check drops the M tail).
 // ------------------------------------------------------------------------------------------------
-template <int NT, int KC, int PRE, bool PADZ>
+// TAIL (NT = 128, KC = 32, Cin = Cout = 128 only): after the 3x3 conv2 of a trunk Fixup block the same
+// workgroup also runs   TAIL >= 1: conv3 (1x1) + scale/bias4 + residual  -> block output (in place over x)
+//                       TAIL == 2: conv1 (1x1) of the NEXT block on that output tile -> its t1.
+// The 128 x 128 activation tile goes accumulator -> LDS ([128][132], over the dead staging buffers) ->
+// A fragments; the 64 KB weight matrices are read as B fragments straight from L2.  This removes the
+// two HBM-bound 1x1 launches per trunk block (4 of the 7 activation passes) with no halo recompute.
+template <int NT, int KC, int PRE, bool PADZ, int TAIL>
 __global__ __launch_bounds__(256, 2)
 void conv_mfma_kernel(const ConvK p) {
     constexpr int LDR = KC + 4;                      // LDS row stride (floats)
@@ -294,6 +305,119 @@ void conv_mfma_kernel(const ConvK p) {
         compute(a_frag, b_frag);
     }
 
+    if constexpr (TAIL > 0) {
+        static_assert(NT == 128 && KC == 32, "fused tail needs the 128-wide tile");
+        constexpr int LDT = 132;
+        float* const T = lds;                               // [128][132], aliases the staging buffers
+        const int li = lane & 31, hh = lane >> 5;
+        const int rows_valid_t = (p.M - m0 < 128) ? (p.M - m0) : 128;
+        const unsigned range_t = (unsigned)rows_valid_t * 128u * 4u;
+
+        auto acc_to_lds = [&]() {                           // accumulator (C/D layout) -> T[row][n]
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        T[(wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * LDT + wn * 64 + ni * 32 + li] = acc[mi][ni][r];
+        };
+        auto gemm_tail = [&](const float* __restrict__ wsrc) {   // acc = T (128 x 128) x wsrc^T, K = 128
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+            const float* af = T + (wm * 64 + li) * LDT + 4 * hh;
+            const float* bf = wsrc + (wn * 64 + li) * 128 + 4 * hh;
+            f32x4 bq[2][4][NI];                             // B fragments, 4 k-slices per group, 2 groups in flight
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) bq[0][u][ni] = *reinterpret_cast<const f32x4*>(bf + ni * 32 * 128 + 8 * u);
+#pragma unroll
+            for (int ug = 0; ug < 4; ++ug) {
+                if (ug + 1 < 4) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni)
+                            bq[(ug + 1) & 1][u][ni] = *reinterpret_cast<const f32x4*>(bf + ni * 32 * 128 + 8 * (4 * (ug + 1) + u));
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    f32x4 a[MI];
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(af + mi * 32 * LDT + 8 * (4 * ug + u));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                            for (int ni = 0; ni < NI; ++ni)
+                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][r], bq[ug & 1][u][ni][r], acc[mi][ni], 0, 0, 0);
+                }
+            }
+        };
+
+        // t2 = ELU(conv2 + b3a) + b3b
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = elu1(acc[mi][ni][r] + p.act_a) + p.act_b;
+        __syncthreads();                                    // every wave is done with the last K-step's tiles
+        acc_to_lds();
+        __syncthreads();
+        gemm_tail(p.w3);                                    // conv3
+
+        // out = conv3 * scale + bias4 + x, in place over the residual stream
+        const __amdgpu_buffer_rsrc_t o_rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(p.y + (int64_t)m0 * 128, 0, (int)range_t, 0x00020000);
+        const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.residual + (int64_t)m0 * 128), 0, (int)range_t, 0x00020000);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const unsigned base = (unsigned)((wm * 64 + mi * 32 + 4 * hh) * 512 + (wn * 64 + ni * 32 + li) * 4);
+                float res[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, base + ((r & 3) + 8 * (r >> 2)) * 512, 0, 0));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float t = acc[mi][ni][r] * p.t_scale;
+                    t = t + p.t_b4;
+                    t = t + res[r];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), o_rsrc, base + ((r & 3) + 8 * (r >> 2)) * 512, 0, 0);
+                    if (TAIL == 2) acc[mi][ni][r] = elu1(t + p.n_b1a) + p.n_b1b;     // next block's conv1 pre-op
+                }
+            }
+        if constexpr (TAIL == 2) {
+            __syncthreads();                                // conv3 finished reading T
+            acc_to_lds();
+            __syncthreads();
+            gemm_tail(p.w1n);                               // next block's conv1
+            const __amdgpu_buffer_rsrc_t t_rsrc =
+                __builtin_amdgcn_make_buffer_rsrc(p.y2 + (int64_t)m0 * 128, 0, (int)range_t, 0x00020000);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const unsigned base = (unsigned)((wm * 64 + mi * 32 + 4 * hh) * 512 + (wn * 64 + ni * 32 + li) * 4);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float t = elu1(acc[mi][ni][r] + p.n_b2a) + p.n_b2b;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), t_rsrc, base + ((r & 3) + 8 * (r >> 2)) * 512, 0, 0);
+                    }
+                }
+        }
+        return;
+    }
+
     // ---- epilogue ---------------------------------------------------------------------------------
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
     // Output / residual rows of this tile are addressed through buffer descriptors based at row m0 whose
@@ -346,20 +470,21 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int cout, int ci
     out[i] = (n < cout) ? w[((int64_t)n * cin + ci) * ks * ks + tap] : 0.f;
 }
 
-template <int NT, int KC, int PRE, bool PADZ>
+template <int NT, int KC, int PRE, bool PADZ, int TAIL = 0>
 int launch(const ConvK& k, hipStream_t stream) {
     const int npad = (int)vqae::round_up(k.Cout, 32);
     dim3 grid((unsigned)vqae::ceil_div(k.M, 128), (unsigned)vqae::ceil_div(npad, NT));
     constexpr int lds_bytes = 2 * (128 + NT) * (KC + 4) * (int)sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)conv_mfma_kernel<NT, KC, PRE, PADZ>,
+        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)conv_mfma_kernel<NT, KC, PRE, PADZ, TAIL>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         attr_set = true;
     }
     const int cls = (NT == 128 && KC == 32 && k.Cin >= 128) ? (k.ks == 3 ? vqae::PROF_CONV3X3_TRUNK : (k.ks == 1 ? vqae::PROF_CONV1X1_TRUNK : 0)) : 0;
-    vqae::ProfScope prof(cls, stream);
-    conv_mfma_kernel<NT, KC, PRE, PADZ><<<grid, 256, lds_bytes, stream>>>(k);
+    const double flops = 2.0 * k.M * (double)k.Cout * ((double)k.Ktot + (TAIL >= 1 ? 128.0 : 0.0) + (TAIL == 2 ? 128.0 : 0.0));
+    vqae::ProfScope prof(cls, stream, flops);
+    conv_mfma_kernel<NT, KC, PRE, PADZ, TAIL><<<grid, 256, lds_bytes, stream>>>(k);
     prof.done();
     VQAE_LAUNCH_CHECK();
     return VQAE_OK;
@@ -409,11 +534,10 @@ extern "C" int vqae_conv_pack_weight_f32(const float* w, int cout, int cin, int 
     return VQAE_OK;
 }
 
-extern "C" int vqae_conv2d_f32(const vqae_conv_args* a, const float* x, const float* w, const float* bias_vec,
-                               const float* residual, float* y, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+namespace {
+int fill_conv(const vqae_conv_args* a, const float* x, const float* w, const float* bias_vec, const float* residual,
+              float* y, ConvK* out, int* kc_out) {
     VQAE_REQUIRE(a, VQAE_ERR_INVALID, "conv2d: null args");
-    if (a->batch == 0) return VQAE_OK;
     VQAE_REQUIRE(x && w && y, VQAE_ERR_INVALID, "conv2d: null pointer");
     VQAE_REQUIRE(a->cin % 8 == 0 && a->cin >= 8, VQAE_ERR_UNSUPPORTED,
                  "conv2d: cin %d must be a multiple of 8 (use vqae_conv3x3_direct_f32 for stems)", a->cin);
@@ -432,9 +556,8 @@ extern "C" int vqae_conv2d_f32(const vqae_conv_args* a, const float* x, const fl
     // 128 / (Ho*Wo) + 2 images)
     VQAE_REQUIRE(((int64_t)128 / (Ho * Wo) + 3) * a->in_h * a->in_w * a->cin < (1ll << 30), VQAE_ERR_UNSUPPORTED,
                  "conv2d: image too large for 32-bit tile-relative offsets");
-    if (M == 0) return VQAE_OK;
-
     ConvK k;
+    memset(&k, 0, sizeof(k));
     k.x = x; k.w = w; k.bias_vec = bias_vec; k.residual = residual; k.y = y;
     k.B = a->batch; k.H = a->in_h; k.W = a->in_w; k.Cin = a->cin; k.Cout = a->cout; k.Ho = Ho; k.Wo = Wo;
     k.ks = a->ksize; k.stride = a->stride; k.pad = a->pad;
@@ -448,8 +571,44 @@ extern "C" int vqae_conv2d_f32(const vqae_conv_args* a, const float* x, const fl
     k.pre_mode = a->pre_mode; k.pre_a = a->pre_a; k.pre_b = a->pre_b;
     k.has_scale = a->has_scale; k.has_bias_s = a->has_bias_s; k.has_act = a->has_act;
     k.scale = a->scale; k.bias_s = a->bias_s; k.act_a = a->act_a; k.act_b = a->act_b;
+    *out = k;
+    *kc_out = kc;
+    return VQAE_OK;
+}
+}  // namespace
 
+extern "C" int vqae_conv2d_f32(const vqae_conv_args* a, const float* x, const float* w, const float* bias_vec,
+                               const float* residual, float* y, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VQAE_REQUIRE(a, VQAE_ERR_INVALID, "conv2d: null args");
+    if (a->batch == 0) return VQAE_OK;
+    ConvK k;
+    int kc;
+    const int rc = fill_conv(a, x, w, bias_vec, residual, y, &k, &kc);
+    if (rc) return rc;
     if (a->cout <= 32) return launch_kc<32>(k, kc, stream);
     if (a->cout <= 64) return launch_kc<64>(k, kc, stream);
     return launch_kc<128>(k, kc, stream);
 }
+
+namespace vqae {
+// Trunk Fixup block tail fusion (internal to the handle): conv2 (3x3 circular, C = 128, `a` carries its
+// geometry and its ELU epilogue) + conv3 (+ the next block's conv1 when w1n != null).
+//   t1 [M][128] -> xio [M][128] updated in place (block output) and, if w1n, t1_next [M][128].
+int conv_trunk_tail(const vqae_conv_args* a, const float* t1, const float* w2, const float* w3, float t_scale,
+                    float t_b4, float* xio, const float* w1n, float n_b1a, float n_b1b, float n_b2a, float n_b2b,
+                    float* t1_next, hipStream_t stream) {
+    if (a->batch == 0) return VQAE_OK;
+    VQAE_REQUIRE(a->cin == 128 && a->cout == 128 && a->ksize == 3 && a->has_act && a->pre_mode == VQAE_PRE_NONE &&
+                 a->pad == 1 && a->pad_mode == VQAE_PAD_CIRCULAR, VQAE_ERR_UNSUPPORTED, "conv_trunk_tail: not a trunk conv2");
+    VQAE_REQUIRE(w3 && xio && (!w1n || t1_next), VQAE_ERR_INVALID, "conv_trunk_tail: null pointer");
+    ConvK k;
+    int kc;
+    const int rc = fill_conv(a, t1, w2, nullptr, xio, xio, &k, &kc);
+    if (rc) return rc;
+    k.w3 = w3; k.w1n = w1n; k.y2 = t1_next;
+    k.t_scale = t_scale; k.t_b4 = t_b4; k.n_b1a = n_b1a; k.n_b1b = n_b1b; k.n_b2a = n_b2a; k.n_b2b = n_b2b;
+    if (w1n) return launch<128, 32, VQAE_PRE_NONE, false, 2>(k, stream);
+    return launch<128, 32, VQAE_PRE_NONE, false, 1>(k, stream);
+}
+}  // namespace vqae

@@ -6,6 +6,7 @@
 // handle (X = residual stream, P/Q/R = block temporaries).
 #include "common.h"
 
+#include <cstdlib>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -15,6 +16,9 @@ char* last_error_buf() {
     static thread_local char buf[512] = {0};
     return buf;
 }
+int conv_trunk_tail(const vqae_conv_args* a, const float* t1, const float* w2, const float* w3, float t_scale,
+                    float t_b4, float* xio, const float* w1n, float n_b1a, float n_b1b, float n_b2a, float n_b2b,
+                    float* t1_next, hipStream_t stream);
 int conv3x3_direct(const void* x, int x_kind, const float* mean255, const float* inv_std255, const float* w,
                    const float* bias, int B, int H, int W, int cin, int cout, float* y, int y_nchw,
                    hipStream_t stream);
@@ -41,11 +45,12 @@ extern "C" int vqae_prof_begin(int kernel_class, int max_launches) {
         }
     }
     p.used = 0;
+    p.work = 0.0;
     p.cls = kernel_class;
     return VQAE_OK;
 }
 
-extern "C" int vqae_prof_end(double* total_ms, int* n_launches) {
+extern "C" int vqae_prof_end(double* total_ms, int* n_launches, double* total_work) {
     vqae::ProfState& p = vqae::prof_state();
     p.cls = 0;
     double tot = 0.0;
@@ -57,6 +62,7 @@ extern "C" int vqae_prof_end(double* total_ms, int* n_launches) {
     }
     if (total_ms) *total_ms = tot;
     if (n_launches) *n_launches = p.used / 2;
+    if (total_work) *total_work = p.work;
     p.used = 0;
     return VQAE_OK;
 }
@@ -95,6 +101,8 @@ struct vqae_handle {
     size_t vq_ws_bytes = 0;
     float* loss_scratch = nullptr;
     bool has_encoder = false, has_decoder = false;
+    bool fuse_trunk = true;                // conv2 + conv3 (+ next conv1) in one launch at the 128-channel trunk
+    bool t1_ready = false;                 // buf[1] already holds the current block's t1
     void* idx_scratch = nullptr;           // indices nobody asked for (vqae_forward with idx == NULL)
     size_t idx_scratch_bytes = 0;
 };
@@ -198,9 +206,28 @@ struct ConvCall {
 
 // PreActFixupResBlock.forward (conv_block.py:196-216) on NHWC buffers.  X holds the input and, on
 // return, buf[0] holds the output (buffers are swapped for down/up).
-int run_block(vqae_handle* h, const Block& b, int B, int& H, int& W, hipStream_t st) {
+int run_block(vqae_handle* h, const Block& b, const Block* next, int B, int& H, int& W, hipStream_t st) {
     float *X = h->buf[0], *P = h->buf[1], *Q = h->buf[2], *R = h->buf[3];
     int rc;
+    if (b.mode == MODE_SAME && b.cin == 128 && b.cout == 128 && h->fuse_trunk) {
+        // trunk: conv1 (unless the previous block's tail already produced t1 in P), then ONE launch for
+        // conv2 + conv3 (+ the next block's conv1 when it is another 128-channel 'same' block)
+        if (!h->t1_ready) {
+            ConvCall c1(B, H, W, b.cin, b.br, 1, 1, 0, VQAE_PAD_NONE);
+            c1.pre(VQAE_PRE_BIAS_ELU_BIAS, b.b1a, b.b1b).act(b.b2a, b.b2b);
+            if ((rc = vqae_conv2d_f32(&c1.a, X, b.w1, nullptr, nullptr, P, st))) return rc;
+        }
+        const bool chain = next && next->mode == MODE_SAME && next->cin == 128 && next->cout == 128;
+        ConvCall c2(B, H, W, b.br, b.br, 3, 1, 1, VQAE_PAD_CIRCULAR);
+        c2.act(b.b3a, b.b3b);
+        if ((rc = vqae::conv_trunk_tail(&c2.a, P, b.w2, b.w3, b.scale, b.b4, X, chain ? next->w1 : nullptr,
+                                        chain ? next->b1a : 0.f, chain ? next->b1b : 0.f, chain ? next->b2a : 0.f,
+                                        chain ? next->b2b : 0.f, chain ? Q : nullptr, st))) return rc;
+        if (chain) std::swap(h->buf[1], h->buf[2]);
+        h->t1_ready = chain;
+        return VQAE_OK;
+    }
+    h->t1_ready = false;
     if (b.mode == MODE_SAME && b.cin == b.cout && vqae_fixup_same_supported(b.cin, H, W)) {
         // high-resolution levels: the whole block in one launch (csrc/fixup_fused.hip), X -> P, swap
         const float sc[8] = {b.b1a, b.b1b, b.b2a, b.b2b, b.b3a, b.b3b, b.b4, b.scale};
@@ -315,8 +342,9 @@ int run_encoder_convs(vqae_handle* h, const void* x, int x_kind, int B, int in_h
     if ((rc = vqae::conv3x3_direct(x, x_kind, kMean255, kInv255, h->stem_w, h->stem_b, B, in_h, in_w,
                                    h->cfg.in_channels, h->cfg.stem, h->buf[0], 0, st))) return rc;
     int H = in_h, W = in_w;
-    for (const Block& b : h->enc)
-        if ((rc = run_block(h, b, B, H, W, st))) return rc;
+    h->t1_ready = false;
+    for (size_t i = 0; i < h->enc.size(); ++i)
+        if ((rc = run_block(h, h->enc[i], i + 1 < h->enc.size() ? &h->enc[i + 1] : nullptr, B, H, W, st))) return rc;
     *zh = H; *zw = W;
     return VQAE_OK;
 }
@@ -343,8 +371,9 @@ int run_vq(vqae_handle* h, int B, int zh, int zw, void* idx, int idx_dtype, floa
 // post_enc blocks + up blocks + out_stem: q in buf[0] -> out (model.py:278-291)
 int run_decoder_convs(vqae_handle* h, int B, int qh, int qw, int layout, float* out, hipStream_t st) {
     int H = qh, W = qw, rc;
-    for (const Block& b : h->dec)
-        if ((rc = run_block(h, b, B, H, W, st))) return rc;
+    h->t1_ready = false;
+    for (size_t i = 0; i < h->dec.size(); ++i)
+        if ((rc = run_block(h, h->dec[i], i + 1 < h->dec.size() ? &h->dec[i + 1] : nullptr, B, H, W, st))) return rc;
     return vqae::conv3x3_direct(h->buf[0], 0, nullptr, nullptr, h->ostem_w, h->ostem_b, B, H, W, h->cfg.stem,
                                 h->cfg.in_channels, out, layout == VQAE_LAYOUT_NCHW ? 1 : 0, st);
 }
@@ -374,6 +403,7 @@ extern "C" int vqae_create(const vqae_config* cfg, const vqae_tensor* tensors, i
 
     vqae_handle* h = new vqae_handle();
     h->cfg = *cfg;
+    h->fuse_trunk = !(getenv("VQAE_NO_TRUNK_FUSION") && atoi(getenv("VQAE_NO_TRUNK_FUSION")));
     h->C = cfg->stem << cfg->n_down;
     h->D = cfg->projection_dim > 0 ? cfg->projection_dim : h->C;
     h->K = cfg->num_embeddings;

@@ -381,7 +381,7 @@ extern "C" int vqae_vq_forward_f32(const float* z, const float* embed, int64_t N
         // evaluation-noise bound between tier-1 sums and the reference recipe's sums
         const float thr = (4.0f * (float)D + 16.0f) * 5.9604645e-8f;
         const unsigned grid = (unsigned)vqae::ceil_div(N, VQ_ROWS_PER_BLOCK);
-        vqae::ProfScope prof(vqae::PROF_VQ_TIER1, stream);
+        vqae::ProfScope prof(vqae::PROF_VQ_TIER1, stream, 3.0 * (double)N * K * D);
         vq_tier1_kernel<<<grid, VQ_WAVES * 64, lds_bytes, stream>>>(z, w.eT, N, K, Kpad, D, thr, w.idx32, margin,
                                                                   w.flag_count, w.flag_list);
         prof.done();

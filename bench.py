@@ -44,6 +44,16 @@ def log(msg):
 T0 = time.perf_counter()
 
 
+def pmc_traffic(kernel_class):
+    """HBM bytes per launch of the dominant kernel from the separate rocprofv3 --pmc passes (FETCH_SIZE
+    doubled per MI355X_MICROARCH.md, + WRITE_SIZE), as summarised in profiles/r01_pmc_traffic.json."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        return d.get(f"class{kernel_class}_bytes_per_launch")
+    except Exception:
+        return None
+
+
 def synth_patches_u8(batch, size, batch_no, device):
     """uint8 ~ U{0..255} NHWC from PCG64(1000 + batch_no)."""
     rng = np.random.Generator(np.random.PCG64(1000 + batch_no))
@@ -165,9 +175,9 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     log(f"timed region done: {dt / args.steps * 1e3:.2f} ms/step")
-    k_ms, k_n = ctypes.c_double(0), ctypes.c_int(0)
+    k_ms, k_n, k_work = ctypes.c_double(0), ctypes.c_int(0), ctypes.c_double(0)
     if prof_on:
-        L.check(lib.vqae_prof_end(ctypes.byref(k_ms), ctypes.byref(k_n)))
+        L.check(lib.vqae_prof_end(ctypes.byref(k_ms), ctypes.byref(k_n), ctypes.byref(k_work)))
 
     if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -199,25 +209,27 @@ def main():
             avg_ms = k_ms.value / k_n.value
             C = spec.channels
             M = B * zh * zh
-            if args.prof_class == 1:      # trunk 3x3 circular conv: 2*M*N*K flops, N = C, K = 9C
-                alg = 2.0 * M * C * 9 * C
-                res["roofline"] = {"kernel": "conv_mfma_kernel<128,32> (3x3 circular, trunk)", "bound": "mfma",
-                                   "achieved": round(alg / (avg_ms * 1e-3) / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                                   "unit": "TFLOP/s", "traffic": None, "launches": k_n.value,
-                                   "avg_ms": round(avg_ms, 4), "alg_flops_per_launch": alg}
+            alg = k_work.value / k_n.value                  # algorithmic work per launch, summed by the library
+            if args.prof_class == 1:
+                # trunk Fixup block kernel: 3x3 circular conv2 (2*M*128*1152) + fused conv3 and next-block
+                # conv1 tails (2*M*128*128 each); M = B*32*32
+                res["roofline"] = {"kernel": "conv_mfma_kernel<128,32,..> (trunk 3x3 conv2 + fused 1x1 tails)",
+                                   "bound": "mfma", "achieved": round(alg / (avg_ms * 1e-3) / 1e12, 2),
+                                   "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "traffic": pmc_traffic(1),
+                                   "launches": k_n.value, "avg_ms": round(avg_ms, 4), "alg_flops_per_launch": alg}
             elif args.prof_class == 2:
-                alg = 2.0 * M * C * C
-                res["roofline"] = {"kernel": "conv_mfma_kernel<128,32> (1x1, trunk)", "bound": "mfma",
+                res["roofline"] = {"kernel": "conv_mfma_kernel<128,32,..> (1x1, trunk)", "bound": "mfma",
                                    "achieved": round(alg / (avg_ms * 1e-3) / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                                    "unit": "TFLOP/s", "traffic": None, "launches": k_n.value,
                                    "avg_ms": round(avg_ms, 4), "alg_flops_per_launch": alg}
-            else:                          # VQ tier 1: algorithmic HBM bytes = N*D*4 read + N idx
-                alg = M * spec.code_dim * 4.0 + M * 4.0
+            else:                          # VQ tier 1: algorithmic HBM bytes = N*D*4 read + N*4 idx; VALU-bound
+                byts = M * spec.code_dim * 4.0 + M * 4.0
                 res["roofline"] = {"kernel": "vq_tier1_kernel", "bound": "hbm",
-                                   "achieved": round(alg / (avg_ms * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS,
+                                   "achieved": round(byts / (avg_ms * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS,
                                    "unit": "GB/s", "traffic": None, "launches": k_n.value,
-                                   "avg_ms": round(avg_ms, 4), "alg_bytes_per_launch": alg,
-                                   "valu_ops_per_launch": 3.0 * M * spec.num_embeddings * spec.code_dim}
+                                   "avg_ms": round(avg_ms, 4), "alg_bytes_per_launch": byts,
+                                   "valu_ops_per_launch": alg,
+                                   "valu_frac_of_78.6Tops": round(alg / (avg_ms * 1e-3) / 78.6e12, 4)}
             res["roofline"]["frac"] = round(res["roofline"]["achieved"] / res["roofline"]["peak"], 4)
         # ---- CPU baseline beside it (rank 0, N = 1 only) -----------------------------------------
         if world == 1 and not args.no_cpu_baseline:

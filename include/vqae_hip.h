@@ -221,11 +221,13 @@ double vqae_flops_per_patch(const vqae_handle* h, int in_h, int in_w, int encode
 
 /* ---------------------------------------------------------------------------------------------
  * 4. Measurement hook (bench.py `roofline`): time every launch of one kernel class with HIP events
- *    recorded on the launch stream.  kernel_class: 1 = trunk 3x3 circular conv (MFMA, cin >= 128),
+ *    recorded on the launch stream.  kernel_class: 1 = trunk 3x3 circular conv (MFMA, cin >= 128; incl. its fused conv3/conv1 tail),
  *    2 = trunk 1x1 conv, 3 = VQ tier-1 argmin.  Not thread-safe; off by default.
  * ------------------------------------------------------------------------------------------- */
 int vqae_prof_begin(int kernel_class, int max_launches);
-int vqae_prof_end(double* total_ms, int* n_launches);
+/* total_work: algorithmic flops of the timed launches (class 1: 2*M*N*K of the 3x3 conv plus, when the
+ * launch also ran the fused conv3 / next-conv1 tail, their 2*M*128*128 each; class 3: 3*N*K*D VALU ops). */
+int vqae_prof_end(double* total_ms, int* n_launches, double* total_work);
 
 #ifdef __cplusplus
 }

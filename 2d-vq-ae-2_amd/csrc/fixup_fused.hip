@@ -11,6 +11,7 @@
 // All three weight matrices stay resident in LDS ([n][k] rows, +4 float pad: conflict-free
 // ds_read_b128 fragments); workgroups are persistent and walk tiles in an XCD-contiguous order.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -232,6 +233,179 @@ int launch_fused(FusedP& p, hipStream_t stream) {
     return VQAE_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// C = 8 / 16: same structure on v_mfma_f32_16x16x4_f32 (A[i = l&15][k = l>>4], B[k = l>>4][j = l&15],
+// D: col = l&15, row = 4*(l>>4) + reg).  A 16-wide N tile wastes nothing at C = 16 (the 32x32x2 form
+// pads N to 32: half the matrix work and half of every epilogue lane were idle) and half at C = 8.
+// Lane (i, q) reads KQ = C/4 consecutive channels at KQ*q and feeds them to KQ MFMAs; the k-th
+// MFMA sums channels {KQ*q' + k : q' = 0..3}, identically permuted for A and B.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int C> struct KVec;
+template <> struct KVec<16> { typedef f32x4 type; };
+template <> struct KVec<8> { typedef f32x2 type; };
+
+template <int C, int TH>
+__global__ __launch_bounds__(256, 3)
+void fixup_same_tiny_kernel(const FusedP p) {
+    using K = FusedCfg<C, TH>;
+    using kvec = typename KVec<C>::type;
+    constexpr int KQ = C / 4;                           // channels per lane per fragment (4 or 2)
+    constexpr int LDT = K::LDT, LDW2 = K::LDW2, HP = K::HP;
+    constexpr int G1 = K::HPP / 16;                     // 16-pixel groups of the halo
+    constexpr int GPW = (G1 + 3) / 4;
+    constexpr int MPW = TH / 4;                         // image rows per wave; 2 M tiles (16 px) each
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const W1s = lds;                             // [16][LDT]
+    float* const W3s = W1s + 32 * LDT;
+    float* const W2s = W3s + 32 * LDT;                  // [16][LDW2]
+    float* const T1 = W2s + 32 * LDW2;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, q = lane >> 4;
+
+    for (int i = tid; i < 16 * (C / 4); i += 256) {
+        const int n = i / (C / 4), c4 = i % (C / 4);
+        *reinterpret_cast<f32x4*>(W1s + n * LDT + 4 * c4) = *reinterpret_cast<const f32x4*>(p.w1 + n * C + 4 * c4);
+        *reinterpret_cast<f32x4*>(W3s + n * LDT + 4 * c4) = *reinterpret_cast<const f32x4*>(p.w3 + n * C + 4 * c4);
+    }
+    for (int i = tid; i < 16 * (9 * C / 4); i += 256) {
+        const int n = i / (9 * C / 4), c4 = i % (9 * C / 4);
+        *reinterpret_cast<f32x4*>(W2s + n * LDW2 + 4 * c4) = *reinterpret_cast<const f32x4*>(p.w2 + n * 9 * C + 4 * c4);
+    }
+    __syncthreads();
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3, per_xcd_wg = (nwg + 7 - xcd) >> 3;
+    const int qq = p.n_tiles >> 3, rr = p.n_tiles & 7;
+    const int xcd_lo = xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq;
+    const int xcd_n = qq + (xcd < rr ? 1 : 0);
+
+    const float* const w1f = W1s + li * LDT + KQ * q;
+    const float* const w3f = W3s + li * LDT + KQ * q;
+    const float* const w2f = W2s + li * LDW2 + KQ * q;
+    const bool n_ok = li < C;
+
+    for (int t = slot; t < xcd_n; t += per_xcd_wg) {
+        const int tile = xcd_lo + t;
+        const int txi = tile % p.tiles_x;
+        const int tyi = (tile / p.tiles_x) % p.tiles_y;
+        const int b = tile / (p.tiles_x * p.tiles_y);
+        const int ty0 = tyi * TH, tx0 = txi * 32;
+        const float* const xim = p.x + (int64_t)b * p.H * p.W * C;
+
+        // ---- P1 ------------------------------------------------------------------------------------
+        const kvec w1v = *reinterpret_cast<const kvec*>(w1f);
+#pragma unroll
+        for (int gi = 0; gi < GPW; ++gi) {
+            const int g = wave + 4 * gi;
+            if (g < G1) {
+                int hp = 16 * g + li;
+                hp = hp < HP ? hp : HP - 1;
+                const int hy = hp / 34, hx = hp - 34 * hy;
+                int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
+                iy = iy < 0 ? iy + p.H : (iy >= p.H ? iy - p.H : iy);
+                ix = ix < 0 ? ix + p.W : (ix >= p.W ? ix - p.W : ix);
+                kvec v = *reinterpret_cast<const kvec*>(xim + ((int64_t)iy * p.W + ix) * C + KQ * q);
+                v = v + p.b1a;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < KQ; ++k) {
+                    const float av = elu1f(v[k]) + p.b1b;
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w1v[k], acc, 0, 0, 0);
+                }
+                if (n_ok) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) T1[(16 * g + 4 * q + r) * LDT + li] = elu1f(acc[r] + p.b2a) + p.b2b;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- P2 ------------------------------------------------------------------------------------
+        f32x4 acc2[MPW][2];
+#pragma unroll
+        for (int mt = 0; mt < MPW; ++mt)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) acc2[mt][hf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap % 3;
+            const kvec bw = *reinterpret_cast<const kvec*>(w2f + tap * C);
+#pragma unroll
+            for (int mt = 0; mt < MPW; ++mt) {
+                const int ry = wave + 4 * mt;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const kvec av = *reinterpret_cast<const kvec*>(T1 + ((ry + dy) * 34 + 16 * hf + li + dx) * LDT + KQ * q);
+#pragma unroll
+                    for (int k = 0; k < KQ; ++k)
+                        acc2[mt][hf] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k], bw[k], acc2[mt][hf], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        if (n_ok) {
+#pragma unroll
+            for (int mt = 0; mt < MPW; ++mt)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        T1[((wave + 4 * mt) * 32 + 16 * hf + 4 * q + r) * LDT + li] = elu1f(acc2[mt][hf][r] + p.b3a) + p.b3b;
+        }
+        __syncthreads();
+
+        // ---- P3 ------------------------------------------------------------------------------------
+        const kvec w3v = *reinterpret_cast<const kvec*>(w3f);
+#pragma unroll
+        for (int mt = 0; mt < MPW; ++mt) {
+            const int ry = wave + 4 * mt;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const kvec av = *reinterpret_cast<const kvec*>(T1 + (ry * 32 + 16 * hf + li) * LDT + KQ * q);
+                f32x4 acc3 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < KQ; ++k) acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k], w3v[k], acc3, 0, 0, 0);
+                if (n_ok) {
+                    const int64_t base = (((int64_t)b * p.H + ty0 + ry) * p.W + tx0 + 16 * hf + 4 * q) * C + li;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float tv = acc3[r] * p.scale;
+                        tv = tv + p.b4;
+                        tv = tv + p.x[base + r * C];
+                        p.y[base + r * C] = tv;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int C, int TH>
+int launch_tiny(FusedP& p, hipStream_t stream) {
+    using K = FusedCfg<C, TH>;
+    constexpr int lds_bytes = K::LDS_FLOATS * (int)sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)fixup_same_tiny_kernel<C, TH>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        attr_set = true;
+    }
+    p.tiles_x = p.W / 32;
+    p.tiles_y = p.H / TH;
+    p.n_tiles = p.B * p.tiles_x * p.tiles_y;
+    int grid = 256 * 3;
+    if (grid > p.n_tiles) grid = p.n_tiles;
+    fixup_same_tiny_kernel<C, TH><<<grid, 256, lds_bytes, stream>>>(p);
+    VQAE_LAUNCH_CHECK();
+    return VQAE_OK;
+}
+
 }  // namespace
 
 extern "C" int vqae_fixup_same_supported(int c, int h, int w) {
@@ -256,7 +430,8 @@ extern "C" int vqae_fixup_same_block_f32(const float* x, float* y, const float* 
     p.B = batch; p.H = h; p.W = w;
     p.b1a = scalars8[0]; p.b1b = scalars8[1]; p.b2a = scalars8[2]; p.b2b = scalars8[3];
     p.b3a = scalars8[4]; p.b3b = scalars8[5]; p.b4 = scalars8[6]; p.scale = scalars8[7];
-    if (c == 8) return launch_fused<8, 8>(p, stream);
-    if (c == 16) return launch_fused<16, 8>(p, stream);
+    static const bool use32 = getenv("VQAE_FUSED_32X32") && atoi(getenv("VQAE_FUSED_32X32"));
+    if (c == 8) return use32 ? launch_fused<8, 8>(p, stream) : launch_tiny<8, 8>(p, stream);
+    if (c == 16) return use32 ? launch_fused<16, 8>(p, stream) : launch_tiny<16, 8>(p, stream);
     return launch_fused<32, 4>(p, stream);
 }

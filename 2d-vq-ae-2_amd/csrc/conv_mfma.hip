@@ -76,11 +76,11 @@ __device__ __forceinline__ float elu1(float v) {
 //     base VGPR + immediate;
 //   * the epilogue addresses through buffer descriptors (hardware range check drops the M tail).
 // ------------------------------------------------------------------------------------------------
-// TAIL (NT = 128, KC = 32, Cin = Cout = 128 only): after the 3x3 conv2 of a trunk Fixup block the same
+// TAIL (KC = 32, Cin = Cout = NT in {64, 128}): after the 3x3 conv2 of a trunk Fixup block the same
 // workgroup also runs   TAIL >= 1: conv3 (1x1) + scale/bias4 + residual  -> block output (in place over x)
 //                       TAIL == 2: conv1 (1x1) of the NEXT block on that output tile -> its t1.
-// The 128 x 128 activation tile goes accumulator -> LDS ([128][132], over the dead staging buffers) ->
-// A fragments; the 64 KB weight matrices are read as B fragments straight from L2.  This removes the
+// The 128 x C activation tile goes accumulator -> LDS ([128][C + 4], over the dead staging buffers) ->
+// A fragments; the C x C weight matrices (<= 64 KB) are read as B fragments straight from L2.  This removes the
 // two HBM-bound 1x1 launches per trunk block (4 of the 7 activation passes) with no halo recompute.
 template <int NT, int KC, int PRE, bool PADZ, int TAIL>
 __global__ __launch_bounds__(256, 2)
@@ -306,12 +306,13 @@ void conv_mfma_kernel(const ConvK p) {
     }
 
     if constexpr (TAIL > 0) {
-        static_assert(NT == 128 && KC == 32, "fused tail needs the 128-wide tile");
-        constexpr int LDT = 132;
-        float* const T = lds;                               // [128][132], aliases the staging buffers
+        static_assert((NT == 128 || NT == 64) && KC == 32, "fused tail: the N tile must cover all C = NT channels");
+        constexpr int CC = NT;                              // channels of the block
+        constexpr int LDT = CC + 4;
+        float* const T = lds;                               // [128][CC + 4], aliases the staging buffers
         const int li = lane & 31, hh = lane >> 5;
         const int rows_valid_t = (p.M - m0 < 128) ? (p.M - m0) : 128;
-        const unsigned range_t = (unsigned)rows_valid_t * 128u * 4u;
+        const unsigned range_t = (unsigned)rows_valid_t * (unsigned)CC * 4u;
 
         auto acc_to_lds = [&]() {                           // accumulator (C/D layout) -> T[row][n]
 #pragma unroll
@@ -320,30 +321,30 @@ void conv_mfma_kernel(const ConvK p) {
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        T[(wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * LDT + wn * 64 + ni * 32 + li] = acc[mi][ni][r];
+                        T[(wm * MI * 32 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * LDT + wn * NI * 32 + ni * 32 + li] = acc[mi][ni][r];
         };
-        auto gemm_tail = [&](const float* __restrict__ wsrc) {   // acc = T (128 x 128) x wsrc^T, K = 128
+        auto gemm_tail = [&](const float* __restrict__ wsrc) {   // acc = T (128 x CC) x wsrc^T, K = CC
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-            const float* af = T + (wm * 64 + li) * LDT + 4 * hh;
-            const float* bf = wsrc + (wn * 64 + li) * 128 + 4 * hh;
+            const float* af = T + (wm * MI * 32 + li) * LDT + 4 * hh;
+            const float* bf = wsrc + (wn * NI * 32 + li) * CC + 4 * hh;
             f32x4 bq[2][4][NI];                             // B fragments, 4 k-slices per group, 2 groups in flight
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) bq[0][u][ni] = *reinterpret_cast<const f32x4*>(bf + ni * 32 * 128 + 8 * u);
+                for (int ni = 0; ni < NI; ++ni) bq[0][u][ni] = *reinterpret_cast<const f32x4*>(bf + ni * 32 * CC + 8 * u);
 #pragma unroll
-            for (int ug = 0; ug < 4; ++ug) {
-                if (ug + 1 < 4) {
+            for (int ug = 0; ug < CC / 32; ++ug) {
+                if (ug + 1 < CC / 32) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
 #pragma unroll
                         for (int ni = 0; ni < NI; ++ni)
-                            bq[(ug + 1) & 1][u][ni] = *reinterpret_cast<const f32x4*>(bf + ni * 32 * 128 + 8 * (4 * (ug + 1) + u));
+                            bq[(ug + 1) & 1][u][ni] = *reinterpret_cast<const f32x4*>(bf + ni * 32 * CC + 8 * (4 * (ug + 1) + u));
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -375,24 +376,24 @@ void conv_mfma_kernel(const ConvK p) {
 
         // out = conv3 * scale + bias4 + x, in place over the residual stream
         const __amdgpu_buffer_rsrc_t o_rsrc =
-            __builtin_amdgcn_make_buffer_rsrc(p.y + (int64_t)m0 * 128, 0, (int)range_t, 0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc(p.y + (int64_t)m0 * CC, 0, (int)range_t, 0x00020000);
         const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(p.residual + (int64_t)m0 * 128), 0, (int)range_t, 0x00020000);
+            const_cast<float*>(p.residual + (int64_t)m0 * CC), 0, (int)range_t, 0x00020000);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
-                const unsigned base = (unsigned)((wm * 64 + mi * 32 + 4 * hh) * 512 + (wn * 64 + ni * 32 + li) * 4);
+                const unsigned base = (unsigned)((wm * MI * 32 + mi * 32 + 4 * hh) * (CC * 4) + (wn * NI * 32 + ni * 32 + li) * 4);
                 float res[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, base + ((r & 3) + 8 * (r >> 2)) * 512, 0, 0));
+                    res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, base + ((r & 3) + 8 * (r >> 2)) * (CC * 4), 0, 0));
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float t = acc[mi][ni][r] * p.t_scale;
                     t = t + p.t_b4;
                     t = t + res[r];
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), o_rsrc, base + ((r & 3) + 8 * (r >> 2)) * 512, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), o_rsrc, base + ((r & 3) + 8 * (r >> 2)) * (CC * 4), 0, 0);
                     if (TAIL == 2) acc[mi][ni][r] = elu1(t + p.n_b1a) + p.n_b1b;     // next block's conv1 pre-op
                 }
             }
@@ -402,16 +403,16 @@ void conv_mfma_kernel(const ConvK p) {
             __syncthreads();
             gemm_tail(p.w1n);                               // next block's conv1
             const __amdgpu_buffer_rsrc_t t_rsrc =
-                __builtin_amdgcn_make_buffer_rsrc(p.y2 + (int64_t)m0 * 128, 0, (int)range_t, 0x00020000);
+                __builtin_amdgcn_make_buffer_rsrc(p.y2 + (int64_t)m0 * CC, 0, (int)range_t, 0x00020000);
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
-                    const unsigned base = (unsigned)((wm * 64 + mi * 32 + 4 * hh) * 512 + (wn * 64 + ni * 32 + li) * 4);
+                    const unsigned base = (unsigned)((wm * MI * 32 + mi * 32 + 4 * hh) * (CC * 4) + (wn * NI * 32 + ni * 32 + li) * 4);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float t = elu1(acc[mi][ni][r] + p.n_b2a) + p.n_b2b;
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), t_rsrc, base + ((r & 3) + 8 * (r >> 2)) * 512, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), t_rsrc, base + ((r & 3) + 8 * (r >> 2)) * (CC * 4), 0, 0);
                     }
                 }
         }
@@ -482,7 +483,7 @@ int launch(const ConvK& k, hipStream_t stream) {
         attr_set = true;
     }
     const int cls = (NT == 128 && KC == 32 && k.Cin >= 128) ? (k.ks == 3 ? vqae::PROF_CONV3X3_TRUNK : (k.ks == 1 ? vqae::PROF_CONV1X1_TRUNK : 0)) : 0;
-    const double flops = 2.0 * k.M * (double)k.Cout * ((double)k.Ktot + (TAIL >= 1 ? 128.0 : 0.0) + (TAIL == 2 ? 128.0 : 0.0));
+    const double flops = 2.0 * k.M * (double)k.Cout * ((double)k.Ktot + (TAIL >= 1 ? (double)k.Cout : 0.0) + (TAIL == 2 ? (double)k.Cout : 0.0));
     vqae::ProfScope prof(cls, stream, flops);
     conv_mfma_kernel<NT, KC, PRE, PADZ, TAIL><<<grid, 256, lds_bytes, stream>>>(k);
     prof.done();
@@ -599,7 +600,7 @@ int conv_trunk_tail(const vqae_conv_args* a, const float* t1, const float* w2, c
                     float t_b4, float* xio, const float* w1n, float n_b1a, float n_b1b, float n_b2a, float n_b2b,
                     float* t1_next, hipStream_t stream) {
     if (a->batch == 0) return VQAE_OK;
-    VQAE_REQUIRE(a->cin == 128 && a->cout == 128 && a->ksize == 3 && a->has_act && a->pre_mode == VQAE_PRE_NONE &&
+    VQAE_REQUIRE((a->cin == 128 || a->cin == 64) && a->cout == a->cin && a->ksize == 3 && a->has_act && a->pre_mode == VQAE_PRE_NONE &&
                  a->pad == 1 && a->pad_mode == VQAE_PAD_CIRCULAR, VQAE_ERR_UNSUPPORTED, "conv_trunk_tail: not a trunk conv2");
     VQAE_REQUIRE(w3 && xio && (!w1n || t1_next), VQAE_ERR_INVALID, "conv_trunk_tail: null pointer");
     ConvK k;
@@ -608,6 +609,10 @@ int conv_trunk_tail(const vqae_conv_args* a, const float* t1, const float* w2, c
     if (rc) return rc;
     k.w3 = w3; k.w1n = w1n; k.y2 = t1_next;
     k.t_scale = t_scale; k.t_b4 = t_b4; k.n_b1a = n_b1a; k.n_b1b = n_b1b; k.n_b2a = n_b2a; k.n_b2b = n_b2b;
+    if (a->cin == 64) {
+        if (w1n) return launch<64, 32, VQAE_PRE_NONE, false, 2>(k, stream);
+        return launch<64, 32, VQAE_PRE_NONE, false, 1>(k, stream);
+    }
     if (w1n) return launch<128, 32, VQAE_PRE_NONE, false, 2>(k, stream);
     return launch<128, 32, VQAE_PRE_NONE, false, 1>(k, stream);
 }

@@ -209,7 +209,7 @@ struct ConvCall {
 int run_block(vqae_handle* h, const Block& b, const Block* next, int B, int& H, int& W, hipStream_t st) {
     float *X = h->buf[0], *P = h->buf[1], *Q = h->buf[2], *R = h->buf[3];
     int rc;
-    if (b.mode == MODE_SAME && b.cin == 128 && b.cout == 128 && h->fuse_trunk) {
+    if (b.mode == MODE_SAME && (b.cin == 128 || b.cin == 64) && b.cout == b.cin && h->fuse_trunk) {
         // trunk: conv1 (unless the previous block's tail already produced t1 in P), then ONE launch for
         // conv2 + conv3 (+ the next block's conv1 when it is another 128-channel 'same' block)
         if (!h->t1_ready) {
@@ -217,7 +217,7 @@ int run_block(vqae_handle* h, const Block& b, const Block* next, int B, int& H, 
             c1.pre(VQAE_PRE_BIAS_ELU_BIAS, b.b1a, b.b1b).act(b.b2a, b.b2b);
             if ((rc = vqae_conv2d_f32(&c1.a, X, b.w1, nullptr, nullptr, P, st))) return rc;
         }
-        const bool chain = next && next->mode == MODE_SAME && next->cin == 128 && next->cout == 128;
+        const bool chain = next && next->mode == MODE_SAME && next->cin == b.cin && next->cout == b.cin;
         ConvCall c2(B, H, W, b.br, b.br, 3, 1, 1, VQAE_PAD_CIRCULAR);
         c2.act(b.b3a, b.b3b);
         if ((rc = vqae::conv_trunk_tail(&c2.a, P, b.w2, b.w3, b.scale, b.b4, X, chain ? next->w1 : nullptr,

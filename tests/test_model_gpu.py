@@ -148,3 +148,19 @@ def test_uint8_ingest_equals_fp32_path(amd, oracle):
     _, idx_f, _ = nat.encode(oracle.normalize_u8(u8).cuda())
     assert torch.equal(idx_u8, idx_f)
     assert np.array_equal(idx_u8.cpu().numpy(), g["idx"].astype(np.int64))
+
+
+def test_trunk_tail_fusion_equals_unfused(amd, oracle, monkeypatch):
+    """conv2 + conv3 + next-block conv1 in one launch (C = 64 / 128 chains) vs the 3-launch path."""
+    g = load_golden("model_B")
+    spec, p = golden_params(oracle, "B", g)
+    x = oracle.make_patches(2, 256, 7).cuda()
+    fused = amd.NativeVQAE(amd.SPECS["B"], p)
+    out_f, idx_f, loss_f = fused.forward(x)
+    monkeypatch.setenv("VQAE_NO_TRUNK_FUSION", "1")
+    plain = amd.NativeVQAE(amd.SPECS["B"], p)
+    out_p, idx_p, loss_p = plain.forward(x)
+    torch.cuda.synchronize()
+    assert torch.equal(idx_f, idx_p)
+    assert float((out_f - out_p).abs().max()) <= 1e-4 * float(out_p.abs().max())
+    assert abs(float(loss_f) - float(loss_p)) <= 1e-6 * float(loss_p)

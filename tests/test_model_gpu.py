@@ -164,3 +164,42 @@ def test_trunk_tail_fusion_equals_unfused(amd, oracle, monkeypatch):
     assert torch.equal(idx_f, idx_p)
     assert float((out_f - out_p).abs().max()) <= 1e-4 * float(out_p.abs().max())
     assert abs(float(loss_f) - float(loss_p)) <= 1e-6 * float(loss_p)
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 32, 32), (3, 64, 96), (5, 96, 32), (2, 128, 128)])
+def test_native_handles_odd_batches_and_non_square_inputs(amd, oracle, B, H, W):
+    """Shapes the reference accepts (any H, W multiple of 2**n_down): fused (W % 32 == 0 levels) and
+    unfused kernels are mixed along the way; compare with the CPU oracle."""
+    spec = oracle.SPECS["tiny"]
+    p = oracle.make_params(spec, 0)
+    g = torch.Generator().manual_seed(B * 1000 + H + W)
+    x = torch.randn(B, 3, H, W, generator=g)
+    p = oracle.calibrate_codebook(x[:1], p, spec)
+    nat = amd.NativeVQAE(amd.SPECS["tiny"], p)
+    out, idx, loss = nat.forward(x.cuda())
+    torch.cuda.synchronize()
+    taps = {}
+    ref_out, ref_loss = oracle.vqae_forward(x, p, spec, taps)
+    assert idx.shape == (B, H // 4, W // 4)
+    same = (idx.cpu() == taps["idx"])
+    assert float(same.float().mean()) >= 0.999
+    if bool(same.all()):
+        assert float(((out.cpu() - ref_out) ** 2).mean()) <= 1e-5
+    assert abs(float(loss) - float(ref_loss[0])) <= 1e-3 * float(ref_loss[0])
+
+
+def test_handle_error_paths(amd, oracle):
+    spec = oracle.SPECS["tiny"]
+    p = oracle.make_params(spec, 0)
+    nat = amd.NativeVQAE(amd.SPECS["tiny"], p)
+    with pytest.raises(AssertionError):                       # 30 is not a multiple of 2**n_down
+        nat.forward(torch.zeros(1, 3, 30, 32).cuda())
+    bad = dict(p)
+    bad.pop("encoder.pre_enc_layers.0.1.bias3a")
+    with pytest.raises(KeyError):                             # missing state-dict entry
+        amd.NativeVQAE(amd.SPECS["tiny"], bad)
+    enc_only = {k: v for k, v in p.items() if k.startswith("encoder.")}
+    e = amd.NativeVQAE(amd.SPECS["tiny"], enc_only)           # `del model.decoder` (extract_embeddings.py:157)
+    q, idx, _ = e.encode(torch.zeros(1, 3, 32, 32).cuda())
+    with pytest.raises(AssertionError):
+        e.decode(q)

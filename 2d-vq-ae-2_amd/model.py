@@ -219,3 +219,13 @@ def default_confs(spec: VQAESpec):
                              "conv_conf": fx},
            "n_post_enc_layers": spec.n_enc, "conv_block_conf": fx, "shortcut_block_conf": None}
     return {"optim_conf": None, "loss_f_conf": None, "encoder_conf": enc, "decoder_conf": dec}
+
+
+def load_lightning_state_dict(path):
+    """state_dict of a Lightning checkpoint written by the reference's training run
+    (`VQAE.load_from_checkpoint`, extract_embeddings.py:156).  Only tensors are read
+    (`weights_only=True`: nothing in the file is executed); the pickled OmegaConf hyper-parameters are
+    NOT loaded -- build the model from a VQAESpec / conf dicts and pass the result to `load_state_dict`."""
+    ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    sd = ckpt.get("state_dict", ckpt) if isinstance(ckpt, dict) else ckpt
+    return {k: v for k, v in sd.items() if isinstance(v, torch.Tensor)}

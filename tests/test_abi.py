@@ -79,3 +79,24 @@ def test_reference_error_types(amd):
         vq(torch.zeros(4, 8))
     with pytest.raises(NotImplementedError):          # vq.py:100-104
         vq(torch.zeros(1, 4, 2, 2))
+
+
+def test_lightning_checkpoint_import(amd, oracle, tmp_path):
+    """A Lightning-style .ckpt ({'state_dict': ...}, reference naming) loads into the mirror model."""
+    import torch
+    from vqae_amd.model import VQAE, load_lightning_state_dict
+    spec = oracle.SPECS["tiny"]
+    p = oracle.make_params(spec, 0)
+    vq = "encoder.vq_layers.0."
+    full = dict(p)
+    full[vq + "embed_avg"] = p[vq + "embed"].clone()
+    full[vq + "cluster_size"] = torch.zeros(spec.num_embeddings)
+    full[vq + "first_pass"] = torch.as_tensor(0)
+    path = tmp_path / "epoch=3-step=100.ckpt"
+    torch.save({"state_dict": full, "epoch": 3, "global_step": 100}, path)
+    sd = load_lightning_state_dict(str(path))
+    m = VQAE.from_spec(amd.SPECS["tiny"])
+    missing, unexpected = m.load_state_dict(sd, strict=True), None
+    got = m.state_dict()
+    for k, v in p.items():
+        assert torch.equal(got[k], v), k

@@ -16,6 +16,22 @@ LAYOUT_NHWC, LAYOUT_NCHW = 0, 1
 IDX_I64, IDX_U8, IDX_U16, IDX_I32 = 0, 1, 2, 3
 PAD_NONE, PAD_CIRCULAR, PAD_ZEROS = 0, 1, 2
 PRE_NONE, PRE_BIAS, PRE_BIAS_ELU_BIAS = 0, 1, 2
+DT_F32, DT_BF16, DT_F16 = 0, 1, 2
+DTYPES = {"f32": DT_F32, "fp32": DT_F32, "float32": DT_F32, "bf16": DT_BF16, "bfloat16": DT_BF16,
+          "f16": DT_F16, "fp16": DT_F16, "float16": DT_F16, "half": DT_F16}
+
+
+def dtype_code(dt):
+    """'bf16' / torch.bfloat16 / None ... -> VQAE_DT_* (autocast semantics, see include/vqae_hip.h)."""
+    if dt is None:
+        return DT_F32
+    if isinstance(dt, int):
+        return dt
+    name = str(dt).replace("torch.", "")
+    try:
+        return DTYPES[name]
+    except KeyError:
+        raise AssertionError(f"unsupported compute dtype {dt}")
 
 
 class VqaeHipError(RuntimeError):
@@ -27,13 +43,13 @@ class ConvArgs(Structure):
                 ("ksize", c_int), ("stride", c_int), ("pad", c_int), ("pad_mode", c_int),
                 ("pre_mode", c_int), ("pre_a", c_float), ("pre_b", c_float),
                 ("has_scale", c_int), ("has_bias_s", c_int), ("has_act", c_int),
-                ("scale", c_float), ("bias_s", c_float), ("act_a", c_float), ("act_b", c_float)]
+                ("scale", c_float), ("bias_s", c_float), ("act_a", c_float), ("act_b", c_float), ("dtype", c_int)]
 
 
 class Config(Structure):
     _fields_ = [("in_channels", c_int), ("stem", c_int), ("n_down", c_int), ("n_pre", c_int), ("n_post", c_int),
                 ("n_enc", c_int), ("num_embeddings", c_int), ("projection_dim", c_int),
-                ("commitment_cost", c_float)]
+                ("commitment_cost", c_float), ("compute_dtype", c_int)]
 
 
 class Tensor(Structure):
@@ -56,9 +72,10 @@ SYMBOLS = {
     "vqae_conv2d_f32": (c_int, [POINTER(ConvArgs), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vqae_fixup_same_supported": (c_int, [c_int, c_int, c_int]),
     "vqae_fixup_same_block_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                                          POINTER(c_float), c_void_p]),
+                                          POINTER(c_float), c_int, c_void_p]),
+    "vqae_round_inplace_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p]),
     "vqae_conv3x3_direct_f32": (c_int, [c_void_p, c_void_p, POINTER(c_float), POINTER(c_float), c_void_p, c_void_p,
-                                        c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+                                        c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "vqae_bicubic_up2_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "vqae_nchw_to_nhwc_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vqae_nhwc_to_nchw_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

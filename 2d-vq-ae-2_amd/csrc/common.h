@@ -64,6 +64,13 @@ struct ProfScope {
     }
 };
 
+// autocast rounding: fp32 value -> nearest bf16 / f16 (RNE) -> fp32
+__device__ __forceinline__ float round_dt(float v, int dt) {
+    if (dt == VQAE_DT_BF16) return (float)(__bf16)v;
+    if (dt == VQAE_DT_F16) return (float)(_Float16)v;
+    return v;
+}
+
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
 

@@ -42,6 +42,7 @@ struct ConvK {
     const float* __restrict__ w1n;       // packed [128][128] of the NEXT block's conv1 (TAIL == 2)
     float* y2;                           // [M][128]: next block's t1 (TAIL == 2)
     float t_scale, t_b4, n_b1a, n_b1b, n_b2a, n_b2b;
+    int dt;                              // VQAE_DT_*: autocast rounding points
 };
 
 // ELU(alpha = 1) = v > 0 ? v : expm1(v), branch-free so the Fixup pre-op / epilogue can be scheduled
@@ -212,6 +213,10 @@ void conv_mfma_kernel(const ConvK p) {
                 }
             }
             if (PADZ) { if ((raz >> i) & 1u) v = (f32x4)(0.f); }
+            if (p.dt) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = vqae::round_dt(v[e], p.dt);       // cast at the conv input
+            }
             *reinterpret_cast<f32x4*>(As + a_wr[i]) = v;
         }
 #pragma unroll
@@ -368,7 +373,8 @@ void conv_mfma_kernel(const ConvK p) {
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = elu1(acc[mi][ni][r] + p.act_a) + p.act_b;
+                for (int r = 0; r < 16; ++r)           // conv2 output cast, fp32 activation, conv3 input cast
+                    acc[mi][ni][r] = vqae::round_dt(elu1(vqae::round_dt(acc[mi][ni][r], p.dt) + p.act_a) + p.act_b, p.dt);
         __syncthreads();                                    // every wave is done with the last K-step's tiles
         acc_to_lds();
         __syncthreads();
@@ -390,11 +396,11 @@ void conv_mfma_kernel(const ConvK p) {
                     res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, base + ((r & 3) + 8 * (r >> 2)) * (CC * 4), 0, 0));
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float t = acc[mi][ni][r] * p.t_scale;
+                    float t = vqae::round_dt(acc[mi][ni][r], p.dt) * p.t_scale;
                     t = t + p.t_b4;
                     t = t + res[r];
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), o_rsrc, base + ((r & 3) + 8 * (r >> 2)) * (CC * 4), 0, 0);
-                    if (TAIL == 2) acc[mi][ni][r] = elu1(t + p.n_b1a) + p.n_b1b;     // next block's conv1 pre-op
+                    if (TAIL == 2) acc[mi][ni][r] = vqae::round_dt(elu1(t + p.n_b1a) + p.n_b1b, p.dt);     // next block's conv1 pre-op
                 }
             }
         if constexpr (TAIL == 2) {
@@ -411,7 +417,7 @@ void conv_mfma_kernel(const ConvK p) {
                     const unsigned base = (unsigned)((wm * MI * 32 + mi * 32 + 4 * hh) * (CC * 4) + (wn * NI * 32 + ni * 32 + li) * 4);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float t = elu1(acc[mi][ni][r] + p.n_b2a) + p.n_b2b;
+                        const float t = elu1(vqae::round_dt(acc[mi][ni][r], p.dt) + p.n_b2a) + p.n_b2b;
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), t_rsrc, base + ((r & 3) + 8 * (r >> 2)) * (CC * 4), 0, 0);
                     }
                 }
@@ -450,9 +456,10 @@ void conv_mfma_kernel(const ConvK p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float t = acc[mi][ni][r];
+                if (p.bias_vec) t = t + bv;                 // the conv's own bias is part of the (16-bit) conv output
+                t = vqae::round_dt(t, p.dt);
                 if (p.has_scale) { t = t * p.scale; t = t + p.bias_s; }
                 else if (p.has_bias_s) { t = t + p.bias_s; }
-                if (p.bias_vec) t = t + bv;
                 if (p.residual) t = t + res[r];
                 if (p.has_act) t = elu1(t + p.act_a) + p.act_b;
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), y_rsrc, base + ((r & 3) + 8 * (r >> 2)) * row_bytes, 0, 0);
@@ -572,6 +579,8 @@ int fill_conv(const vqae_conv_args* a, const float* x, const float* w, const flo
     k.pre_mode = a->pre_mode; k.pre_a = a->pre_a; k.pre_b = a->pre_b;
     k.has_scale = a->has_scale; k.has_bias_s = a->has_bias_s; k.has_act = a->has_act;
     k.scale = a->scale; k.bias_s = a->bias_s; k.act_a = a->act_a; k.act_b = a->act_b;
+    VQAE_REQUIRE(a->dtype >= VQAE_DT_F32 && a->dtype <= VQAE_DT_F16, VQAE_ERR_INVALID, "conv2d: dtype %d", a->dtype);
+    k.dt = a->dtype;
     *out = k;
     *kc_out = kc;
     return VQAE_OK;

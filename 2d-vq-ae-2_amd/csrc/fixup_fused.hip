@@ -27,6 +27,7 @@ struct FusedP {
     int B, H, W;
     int tiles_x, tiles_y, n_tiles;
     float b1a, b1b, b2a, b2b, b3a, b3b, b4, scale;
+    int dt;                              // VQAE_DT_*: autocast rounding points
 };
 
 __device__ __forceinline__ float elu1f(float v) {      // see conv_mfma.hip
@@ -128,7 +129,7 @@ void fixup_same_small_kernel(const FusedP p) {
                 for (int u = 0; u < C / 8; ++u) {
                     f32x4 v = a[u] + p.b1a;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = elu1f(v[e]) + p.b1b;
+                    for (int e = 0; e < 4; ++e) v[e] = vqae::round_dt(elu1f(v[e]) + p.b1b, p.dt);
                     const f32x4 bw = *reinterpret_cast<const f32x4*>(w1f + 8 * u);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[r], bw[r], acc, 0, 0, 0);
@@ -137,7 +138,7 @@ void fixup_same_small_kernel(const FusedP p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                        T1[(32 * g + row) * LDT + li] = elu1f(acc[r] + p.b2a) + p.b2b;
+                        T1[(32 * g + row) * LDT + li] = vqae::round_dt(elu1f(vqae::round_dt(acc[r], p.dt) + p.b2a) + p.b2b, p.dt);
                     }
                 }
             }
@@ -174,7 +175,7 @@ void fixup_same_small_kernel(const FusedP p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    T1[(ry * 32 + row) * LDT + li] = elu1f(acc2[mt][r] + p.b3a) + p.b3b;   // t2 over t1
+                    T1[(ry * 32 + row) * LDT + li] = vqae::round_dt(elu1f(vqae::round_dt(acc2[mt][r], p.dt) + p.b3a) + p.b3b, p.dt);   // t2 over t1
                 }
             }
         }
@@ -201,7 +202,7 @@ void fixup_same_small_kernel(const FusedP p) {
                 for (int r = 0; r < 16; ++r) res[r] = p.x[rowbase + ((r & 3) + 8 * (r >> 2) + 4 * h) * C];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float tv = acc3[r] * p.scale;
+                    float tv = vqae::round_dt(acc3[r], p.dt) * p.scale;
                     tv = tv + p.b4;
                     tv = tv + res[r];
                     p.y[rowbase + ((r & 3) + 8 * (r >> 2) + 4 * h) * C] = tv;
@@ -314,12 +315,13 @@ void fixup_same_tiny_kernel(const FusedP p) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int k = 0; k < KQ; ++k) {
-                    const float av = elu1f(v[k]) + p.b1b;
+                    const float av = vqae::round_dt(elu1f(v[k]) + p.b1b, p.dt);
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w1v[k], acc, 0, 0, 0);
                 }
                 if (n_ok) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) T1[(16 * g + 4 * q + r) * LDT + li] = elu1f(acc[r] + p.b2a) + p.b2b;
+                    for (int r = 0; r < 4; ++r)
+                        T1[(16 * g + 4 * q + r) * LDT + li] = vqae::round_dt(elu1f(vqae::round_dt(acc[r], p.dt) + p.b2a) + p.b2b, p.dt);
                 }
             }
         }
@@ -355,7 +357,8 @@ void fixup_same_tiny_kernel(const FusedP p) {
                 for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        T1[((wave + 4 * mt) * 32 + 16 * hf + 4 * q + r) * LDT + li] = elu1f(acc2[mt][hf][r] + p.b3a) + p.b3b;
+                        T1[((wave + 4 * mt) * 32 + 16 * hf + 4 * q + r) * LDT + li] =
+                            vqae::round_dt(elu1f(vqae::round_dt(acc2[mt][hf][r], p.dt) + p.b3a) + p.b3b, p.dt);
         }
         __syncthreads();
 
@@ -374,7 +377,7 @@ void fixup_same_tiny_kernel(const FusedP p) {
                     const int64_t base = (((int64_t)b * p.H + ty0 + ry) * p.W + tx0 + 16 * hf + 4 * q) * C + li;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float tv = acc3[r] * p.scale;
+                        float tv = vqae::round_dt(acc3[r], p.dt) * p.scale;
                         tv = tv + p.b4;
                         tv = tv + p.x[base + r * C];
                         p.y[base + r * C] = tv;
@@ -417,7 +420,7 @@ extern "C" int vqae_fixup_same_supported(int c, int h, int w) {
 
 extern "C" int vqae_fixup_same_block_f32(const float* x, float* y, const float* w1_packed, const float* w2_packed,
                                          const float* w3_packed, int batch, int h, int w, int c,
-                                         const float* scalars8, void* stream_) {
+                                         const float* scalars8, int dtype, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     VQAE_REQUIRE(scalars8, VQAE_ERR_INVALID, "fixup_same_block: null scalars");
     if (batch == 0) return VQAE_OK;
@@ -430,6 +433,8 @@ extern "C" int vqae_fixup_same_block_f32(const float* x, float* y, const float* 
     p.B = batch; p.H = h; p.W = w;
     p.b1a = scalars8[0]; p.b1b = scalars8[1]; p.b2a = scalars8[2]; p.b2b = scalars8[3];
     p.b3a = scalars8[4]; p.b3b = scalars8[5]; p.b4 = scalars8[6]; p.scale = scalars8[7];
+    VQAE_REQUIRE(dtype >= VQAE_DT_F32 && dtype <= VQAE_DT_F16, VQAE_ERR_INVALID, "fixup_same_block: dtype %d", dtype);
+    p.dt = dtype;
     static const bool use32 = getenv("VQAE_FUSED_32X32") && atoi(getenv("VQAE_FUSED_32X32"));
     if (c == 8) return use32 ? launch_fused<8, 8>(p, stream) : launch_tiny<8, 8>(p, stream);
     if (c == 16) return use32 ? launch_fused<16, 8>(p, stream) : launch_tiny<16, 8>(p, stream);

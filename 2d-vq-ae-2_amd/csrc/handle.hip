@@ -20,7 +20,7 @@ int conv_trunk_tail(const vqae_conv_args* a, const float* t1, const float* w2, c
                     float t_b4, float* xio, const float* w1n, float n_b1a, float n_b1b, float n_b2a, float n_b2b,
                     float* t1_next, hipStream_t stream);
 int conv3x3_direct(const void* x, int x_kind, const float* mean255, const float* inv_std255, const float* w,
-                   const float* bias, int B, int H, int W, int cin, int cout, float* y, int y_nchw,
+                   const float* bias, int B, int H, int W, int cin, int cout, float* y, int y_nchw, int dt,
                    hipStream_t stream);
 }  // namespace vqae
 
@@ -150,6 +150,7 @@ int upload_packed(vqae_handle* h, const float* host, int cout, int cin, int ks, 
     int rc = (e == hipSuccess) ? dev_alloc(h, vqae_conv_packed_floats(cout, cin, ks) * 4, &packed)
                                : vqae::fail(VQAE_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(e));
     if (rc == VQAE_OK) rc = vqae_conv_pack_weight_f32(raw, cout, cin, ks, (float*)packed, nullptr);
+    if (rc == VQAE_OK) rc = vqae_round_inplace_f32((float*)packed, (int64_t)vqae_conv_packed_floats(cout, cin, ks), h->cfg.compute_dtype, nullptr);
     if (rc == VQAE_OK && hipDeviceSynchronize() != hipSuccess) rc = vqae::fail(VQAE_ERR_HIP, "pack sync failed");
     (void)hipFree(tmp);
     *out = (float*)packed;
@@ -191,10 +192,14 @@ int load_block(vqae_handle* h, const TensorMap& tm, const std::string& pre, int 
 }
 
 // ---- one conv launch --------------------------------------------------------------------------
+// compute dtype of the handle currently executing (set at the top of every entry point; handles are not
+// shared across threads)
+thread_local int g_dt = VQAE_DT_F32;
 struct ConvCall {
     vqae_conv_args a;
-    ConvCall(int B, int H, int W, int cin, int cout, int ks, int stride, int pad, int pad_mode) {
+    ConvCall(int B, int H, int W, int cin, int cout, int ks, int stride, int pad, int pad_mode, int dt = g_dt) {
         memset(&a, 0, sizeof(a));
+        a.dtype = dt;
         a.batch = B; a.in_h = H; a.in_w = W; a.cin = cin; a.cout = cout;
         a.ksize = ks; a.stride = stride; a.pad = pad; a.pad_mode = pad_mode;
     }
@@ -231,7 +236,7 @@ int run_block(vqae_handle* h, const Block& b, const Block* next, int B, int& H, 
     if (b.mode == MODE_SAME && b.cin == b.cout && vqae_fixup_same_supported(b.cin, H, W)) {
         // high-resolution levels: the whole block in one launch (csrc/fixup_fused.hip), X -> P, swap
         const float sc[8] = {b.b1a, b.b1b, b.b2a, b.b2b, b.b3a, b.b3b, b.b4, b.scale};
-        if ((rc = vqae_fixup_same_block_f32(X, P, b.w1, b.w2, b.w3, B, H, W, b.cin, sc, st))) return rc;
+        if ((rc = vqae_fixup_same_block_f32(X, P, b.w1, b.w2, b.w3, B, H, W, b.cin, sc, g_dt, st))) return rc;
         std::swap(h->buf[0], h->buf[1]);
         return VQAE_OK;
     }
@@ -340,7 +345,7 @@ int run_encoder_convs(vqae_handle* h, const void* x, int x_kind, int B, int in_h
                       hipStream_t st) {
     int rc;
     if ((rc = vqae::conv3x3_direct(x, x_kind, kMean255, kInv255, h->stem_w, h->stem_b, B, in_h, in_w,
-                                   h->cfg.in_channels, h->cfg.stem, h->buf[0], 0, st))) return rc;
+                                   h->cfg.in_channels, h->cfg.stem, h->buf[0], 0, g_dt, st))) return rc;
     int H = in_h, W = in_w;
     h->t1_ready = false;
     for (size_t i = 0; i < h->enc.size(); ++i)
@@ -375,7 +380,7 @@ int run_decoder_convs(vqae_handle* h, int B, int qh, int qw, int layout, float* 
     for (size_t i = 0; i < h->dec.size(); ++i)
         if ((rc = run_block(h, h->dec[i], i + 1 < h->dec.size() ? &h->dec[i + 1] : nullptr, B, H, W, st))) return rc;
     return vqae::conv3x3_direct(h->buf[0], 0, nullptr, nullptr, h->ostem_w, h->ostem_b, B, H, W, h->cfg.stem,
-                                h->cfg.in_channels, out, layout == VQAE_LAYOUT_NCHW ? 1 : 0, st);
+                                h->cfg.in_channels, out, layout == VQAE_LAYOUT_NCHW ? 1 : 0, g_dt, st);
 }
 
 int export_q(vqae_handle* h, int B, int zh, int zw, int layout, float* q, hipStream_t st) {
@@ -398,6 +403,8 @@ extern "C" int vqae_create(const vqae_config* cfg, const vqae_tensor* tensors, i
                  cfg->num_embeddings);
     VQAE_REQUIRE(cfg->projection_dim == 0 || (cfg->projection_dim % 8 == 0), VQAE_ERR_UNSUPPORTED,
                  "projection_dim %d must be 0 or a multiple of 8", cfg->projection_dim);
+    VQAE_REQUIRE(cfg->compute_dtype >= VQAE_DT_F32 && cfg->compute_dtype <= VQAE_DT_F16, VQAE_ERR_INVALID,
+                 "compute_dtype %d", cfg->compute_dtype);
     TensorMap tm;
     for (int i = 0; i < n_tensors; ++i) tm[tensors[i].name] = &tensors[i];
 
@@ -452,8 +459,10 @@ extern "C" int vqae_create(const vqae_config* cfg, const vqae_tensor* tensors, i
         if (cfg->projection_dim > 0) {
             if ((rc = find(tm, vq + "proj_in.weight", (int64_t)h->D * h->C, &p)) || (rc = upload_packed(h, p, h->D, h->C, 1, &h->pin_w))) return bail(rc);
             if ((rc = find(tm, vq + "proj_in.bias", h->D, &p)) || (rc = upload(h, p, h->D, &h->pin_b))) return bail(rc);
+            if ((rc = vqae_round_inplace_f32(h->pin_b, h->D, cfg->compute_dtype, nullptr))) return bail(rc);
             if ((rc = find(tm, vq + "proj_out.weight", (int64_t)h->C * h->D, &p)) || (rc = upload_packed(h, p, h->C, h->D, 1, &h->pout_w))) return bail(rc);
             if ((rc = find(tm, vq + "proj_out.bias", h->C, &p)) || (rc = upload(h, p, h->C, &h->pout_b))) return bail(rc);
+            if ((rc = vqae_round_inplace_f32(h->pout_b, h->C, cfg->compute_dtype, nullptr))) return bail(rc);
         }
     }
     if (has_dec) {
@@ -517,6 +526,7 @@ extern "C" int vqae_set_codebook(vqae_handle* h, const float* embed_host) {
 
 static int encode_impl(vqae_handle* h, const void* x, int x_kind, int B, int in_h, int in_w, void* idx, int idx_dtype,
                        float* q, int q_layout, float* loss, hipStream_t st) {
+    if (h) g_dt = h->cfg.compute_dtype;
     VQAE_REQUIRE(h && x && idx, VQAE_ERR_INVALID, "vqae_encode: null pointer");
     VQAE_REQUIRE(h->has_encoder, VQAE_ERR_INVALID, "vqae_encode: handle was created without encoder.* tensors");
     int rc = check_geometry(h, B, in_h, in_w);
@@ -542,6 +552,7 @@ extern "C" int vqae_encode_u8(vqae_handle* h, const uint8_t* x, int B, int in_h,
 
 extern "C" int vqae_encode_features(vqae_handle* h, const float* x, int B, int in_h, int in_w, int layout, float* z,
                                     void* stream) {
+    if (h) g_dt = h->cfg.compute_dtype;
     hipStream_t st = (hipStream_t)stream;
     VQAE_REQUIRE(h && x && z, VQAE_ERR_INVALID, "vqae_encode_features: null pointer");
     VQAE_REQUIRE(h->has_encoder, VQAE_ERR_INVALID, "vqae_encode_features: handle has no encoder");
@@ -560,6 +571,7 @@ extern "C" int vqae_encode_features(vqae_handle* h, const float* x, int B, int i
 }
 
 extern "C" int vqae_decode(vqae_handle* h, const float* q, int B, int qh, int qw, int layout, float* out, void* stream) {
+    if (h) g_dt = h->cfg.compute_dtype;
     hipStream_t st = (hipStream_t)stream;
     VQAE_REQUIRE(h && q && out, VQAE_ERR_INVALID, "vqae_decode: null pointer");
     VQAE_REQUIRE(h->has_decoder, VQAE_ERR_INVALID, "vqae_decode: handle was created without decoder.* tensors");
@@ -577,6 +589,7 @@ extern "C" int vqae_decode(vqae_handle* h, const float* q, int B, int qh, int qw
 
 extern "C" int vqae_decode_indices(vqae_handle* h, const void* idx, int idx_dtype, int B, int qh, int qw, int layout,
                                    float* out, void* stream) {
+    if (h) g_dt = h->cfg.compute_dtype;
     hipStream_t st = (hipStream_t)stream;
     VQAE_REQUIRE(h && idx && out, VQAE_ERR_INVALID, "vqae_decode_indices: null pointer");
     VQAE_REQUIRE(h->has_decoder && h->embed, VQAE_ERR_INVALID, "vqae_decode_indices: handle needs decoder.* tensors and a codebook");
@@ -597,6 +610,7 @@ extern "C" int vqae_decode_indices(vqae_handle* h, const void* idx, int idx_dtyp
 
 extern "C" int vqae_forward(vqae_handle* h, const float* x, int B, int in_h, int in_w, int layout, float* out, void* idx,
                             int idx_dtype, float* loss, void* stream) {
+    if (h) g_dt = h->cfg.compute_dtype;
     hipStream_t st = (hipStream_t)stream;
     VQAE_REQUIRE(h && x && out, VQAE_ERR_INVALID, "vqae_forward: null pointer");
     VQAE_REQUIRE(h->has_encoder && h->has_decoder, VQAE_ERR_INVALID, "vqae_forward: handle needs encoder.* and decoder.* tensors");

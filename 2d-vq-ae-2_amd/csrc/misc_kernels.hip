@@ -16,13 +16,14 @@ struct Norm3 { float mean[4]; float inv[4]; };
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256)
 void conv3x3_direct_kernel(const void* __restrict__ xin, int x_kind, Norm3 nrm, const float* __restrict__ w,
-                           const float* __restrict__ bias, int B, int H, int W, float* __restrict__ y, int y_nchw) {
+                           const float* __restrict__ bias, int B, int H, int W, float* __restrict__ y, int y_nchw,
+                           int dt) {
     __shared__ float ws[9 * CIN * COUT + COUT];          // [tap][ci][co], then bias
     for (int i = threadIdx.x; i < 9 * CIN * COUT; i += 256) {
         const int co = i % COUT, ci = (i / COUT) % CIN, tap = i / (COUT * CIN);
-        ws[i] = w[((int64_t)co * CIN + ci) * 9 + tap];   // PyTorch [co][ci][kh][kw]
+        ws[i] = vqae::round_dt(w[((int64_t)co * CIN + ci) * 9 + tap], dt);   // PyTorch [co][ci][kh][kw]
     }
-    for (int i = threadIdx.x; i < COUT; i += 256) ws[9 * CIN * COUT + i] = bias[i];
+    for (int i = threadIdx.x; i < COUT; i += 256) ws[9 * CIN * COUT + i] = vqae::round_dt(bias[i], dt);
     __syncthreads();
 
     const int64_t npix = (int64_t)B * H * W;
@@ -66,6 +67,10 @@ void conv3x3_direct_kernel(const void* __restrict__ xin, int x_kind, Norm3 nrm, 
 #pragma unroll
                 for (int c = 0; c < CIN; ++c) xv[c] = ((float)src[c] - nrm.mean[c & 3]) * nrm.inv[c & 3];
             }
+            if (dt) {
+#pragma unroll
+                for (int c = 0; c < CIN; ++c) xv[c] = vqae::round_dt(xv[c], dt);
+            }
 #pragma unroll
             for (int c = 0; c < CIN; ++c) {
                 const float* wr = ws + (tap * CIN + c) * COUT;
@@ -73,6 +78,10 @@ void conv3x3_direct_kernel(const void* __restrict__ xin, int x_kind, Norm3 nrm, 
                 for (int co = 0; co < COUT; ++co) acc[co] = __builtin_fmaf(xv[c], wr[co], acc[co]);
             }
         }
+    }
+    if (dt) {
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[co] = vqae::round_dt(acc[co], dt);
     }
     if (y_nchw) {
 #pragma unroll
@@ -188,10 +197,10 @@ void stitch_kernel(const TI* __restrict__ tiles, const int32_t* __restrict__ rc,
 
 template <int CIN, int COUT>
 int launch_direct(const void* x, int x_kind, const Norm3& nrm, const float* w, const float* bias, int B, int H, int W,
-                  float* y, int y_nchw, hipStream_t stream) {
+                  float* y, int y_nchw, int dt, hipStream_t stream) {
     const int64_t npix = (int64_t)B * H * W;
     conv3x3_direct_kernel<CIN, COUT><<<(unsigned)vqae::ceil_div(npix, 256), 256, 0, stream>>>(
-        x, x_kind, nrm, w, bias, B, H, W, y, y_nchw);
+        x, x_kind, nrm, w, bias, B, H, W, y, y_nchw, dt);
     VQAE_LAUNCH_CHECK();
     return VQAE_OK;
 }
@@ -216,7 +225,7 @@ int stitch_out(const TI* tiles, const int32_t* rc, int64_t total, int th, int tw
 namespace vqae {
 // internal entry shared with handle.hip: x_kind 0 NHWC f32 / 1 NCHW f32 / 2 u8 NHWC; y_nchw 0/1
 int conv3x3_direct(const void* x, int x_kind, const float* mean255, const float* inv_std255, const float* w,
-                   const float* bias, int B, int H, int W, int cin, int cout, float* y, int y_nchw,
+                   const float* bias, int B, int H, int W, int cin, int cout, float* y, int y_nchw, int dt,
                    hipStream_t stream) {
     Norm3 nrm;
     for (int i = 0; i < 4; ++i) {
@@ -227,7 +236,7 @@ int conv3x3_direct(const void* x, int x_kind, const float* mean255, const float*
     VQAE_REQUIRE(x_kind != 2 || cin == 3, VQAE_ERR_UNSUPPORTED, "conv3x3_direct: uint8 input needs cin == 3");
     if ((int64_t)B * H * W == 0) return VQAE_OK;
 #define VQAE_DIRECT_CASE(CI, CO) \
-    if (cin == CI && cout == CO) return launch_direct<CI, CO>(x, x_kind, nrm, w, bias, B, H, W, y, y_nchw, stream);
+    if (cin == CI && cout == CO) return launch_direct<CI, CO>(x, x_kind, nrm, w, bias, B, H, W, y, y_nchw, dt, stream);
     VQAE_DIRECT_CASE(3, 4) VQAE_DIRECT_CASE(3, 8) VQAE_DIRECT_CASE(3, 16) VQAE_DIRECT_CASE(3, 32) VQAE_DIRECT_CASE(3, 64)
     VQAE_DIRECT_CASE(4, 3) VQAE_DIRECT_CASE(8, 3) VQAE_DIRECT_CASE(16, 3) VQAE_DIRECT_CASE(32, 3) VQAE_DIRECT_CASE(64, 3)
 #undef VQAE_DIRECT_CASE
@@ -237,10 +246,27 @@ int conv3x3_direct(const void* x, int x_kind, const float* mean255, const float*
 
 extern "C" int vqae_conv3x3_direct_f32(const float* x, const uint8_t* x_u8, const float* mean255, const float* inv_std255,
                                        const float* w, const float* bias, int B, int H, int W, int cin, int cout,
-                                       float* y, void* stream) {
+                                       float* y, int dtype, void* stream) {
+    VQAE_REQUIRE(dtype >= VQAE_DT_F32 && dtype <= VQAE_DT_F16, VQAE_ERR_INVALID, "conv3x3_direct: dtype %d", dtype);
     if (x_u8)
-        return vqae::conv3x3_direct(x_u8, 2, mean255, inv_std255, w, bias, B, H, W, cin, cout, y, 0, (hipStream_t)stream);
-    return vqae::conv3x3_direct(x, 0, nullptr, nullptr, w, bias, B, H, W, cin, cout, y, 0, (hipStream_t)stream);
+        return vqae::conv3x3_direct(x_u8, 2, mean255, inv_std255, w, bias, B, H, W, cin, cout, y, 0, dtype, (hipStream_t)stream);
+    return vqae::conv3x3_direct(x, 0, nullptr, nullptr, w, bias, B, H, W, cin, cout, y, 0, dtype, (hipStream_t)stream);
+}
+
+namespace {
+__global__ void round_inplace_kernel(float* __restrict__ x, int64_t n, int dt) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[i] = vqae::round_dt(x[i], dt);
+}
+}  // namespace
+
+extern "C" int vqae_round_inplace_f32(float* x, int64_t n, int dtype, void* stream) {
+    VQAE_REQUIRE(dtype >= VQAE_DT_F32 && dtype <= VQAE_DT_F16, VQAE_ERR_INVALID, "round_inplace: dtype %d", dtype);
+    if (n == 0 || dtype == VQAE_DT_F32) return VQAE_OK;
+    VQAE_REQUIRE(x, VQAE_ERR_INVALID, "round_inplace: null pointer");
+    round_inplace_kernel<<<(unsigned)vqae::ceil_div(n, 256), 256, 0, (hipStream_t)stream>>>(x, n, dtype);
+    VQAE_LAUNCH_CHECK();
+    return VQAE_OK;
 }
 
 extern "C" int vqae_bicubic_up2_f32(const float* x, int B, int H, int W, int C, float pre_bias, float* y, void* stream_) {

@@ -59,11 +59,22 @@ class _NativeMixin:
     def _spec(self) -> VQAESpec:
         raise NotImplementedError
 
+    @staticmethod
+    def _autocast_dtype():
+        """The reference's extraction runs `with torch.autocast('cuda')` (extract_embeddings.py:124-125);
+        inside such a context the mirrors use the matching 16-bit autocast handle."""
+        if torch.is_autocast_enabled():
+            return torch.get_autocast_gpu_dtype()
+        return None
+
     def native(self) -> NativeVQAE:
+        dt = self._autocast_dtype()
         if self._native is None:
+            self._native = {}
+        if dt not in self._native:
             sd = {self._prefix + k: v for k, v in self.state_dict().items()}
-            self._native = NativeVQAE(self._spec(), sd)
-        return self._native
+            self._native[dt] = NativeVQAE(self._spec(), sd, compute_dtype=dt)
+        return self._native[dt]
 
     def refresh(self):
         """Drop the device snapshot of the weights (call after changing parameters)."""
@@ -167,9 +178,9 @@ class VQAE(_NativeMixin, nn.Module):
 
     def native(self):
         n = super().native()
-        self.encoder._native = n          # share one device copy of the weights
+        self.encoder._native = self._native          # share the device copies of the weights
         if self.decoder is not None:
-            self.decoder._native = n
+            self.decoder._native = self._native
         return n
 
     def forward(self, data: torch.Tensor):

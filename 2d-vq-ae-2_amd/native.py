@@ -15,10 +15,13 @@ class NativeVQAE:
     """Owns a vqae_handle built from a {state-dict name: tensor} mapping in the reference's naming
     (SURVEY.md §5).  One handle per process/device; not thread-safe."""
 
-    def __init__(self, spec: VQAESpec, state_dict):
+    def __init__(self, spec: VQAESpec, state_dict, compute_dtype=None):
+        """compute_dtype: None/'f32', or 'bf16' / 'f16' (torch dtypes accepted): torch.autocast semantics
+        for the convolutions (16-bit operands and conv outputs, fp32 accumulation, fp32 everything else)."""
         self.spec = spec
+        self.compute_dtype = L.dtype_code(compute_dtype)
         cfg = L.Config(spec.in_channels, spec.stem, spec.n_down, spec.n_pre, spec.n_post, spec.n_enc,
-                       spec.num_embeddings, spec.projection_dim, float(spec.commitment_cost))
+                       spec.num_embeddings, spec.projection_dim, float(spec.commitment_cost), self.compute_dtype)
         keep, items = [], []
         for name, t in state_dict.items():
             if name.endswith(_BUFFER_ONLY):

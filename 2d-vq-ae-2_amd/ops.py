@@ -50,19 +50,21 @@ def nhwc_to_nchw(x):
     return y
 
 
-def pack_conv_weight(w):
-    """[cout][cin][k][k] (PyTorch) -> the MFMA kernel's packed layout."""
+def pack_conv_weight(w, dtype=None):
+    """[cout][cin][k][k] (PyTorch) -> the MFMA kernel's packed layout; `dtype` ('bf16'/'f16') rounds the
+    weights to that type (autocast casts conv weights)."""
     _need_gpu(w)
     w = w.contiguous().float()
     cout, cin, k, _ = w.shape
     n = L.lib().vqae_conv_packed_floats(cout, cin, k)
     out = torch.empty(n, dtype=torch.float32, device=w.device)
     L.check(L.lib().vqae_conv_pack_weight_f32(_p(w), cout, cin, k, _p(out), _stream()))
+    L.check(L.lib().vqae_round_inplace_f32(_p(out), n, L.dtype_code(dtype), _stream()))
     return out
 
 
 def conv2d(x, w_packed, cout, ksize, stride=1, pad=0, pad_mode=L.PAD_NONE, pre=None, act=None, scale_bias=None,
-           bias_s=None, bias_vec=None, residual=None, out=None):
+           bias_s=None, bias_vec=None, residual=None, out=None, dtype=None):
     """NHWC fp32 conv through vqae_conv2d_f32.  pre = (a,) or (a, b); act = (a, b); scale_bias = (s, b)."""
     _need_gpu(x, w_packed)
     x = x.contiguous()
@@ -70,6 +72,7 @@ def conv2d(x, w_packed, cout, ksize, stride=1, pad=0, pad_mode=L.PAD_NONE, pre=N
     a = L.ConvArgs()
     a.batch, a.in_h, a.in_w, a.cin, a.cout = B, H, W, cin, cout
     a.ksize, a.stride, a.pad, a.pad_mode = ksize, stride, pad, pad_mode
+    a.dtype = L.dtype_code(dtype)
     if pre is not None:
         if len(pre) == 1:
             a.pre_mode, a.pre_a = L.PRE_BIAS, float(pre[0])
@@ -94,18 +97,19 @@ def fixup_same_supported(c, h, w):
     return bool(L.lib().vqae_fixup_same_supported(c, h, w))
 
 
-def fixup_same_block(x, w1p, w2p, w3p, scalars8):
+def fixup_same_block(x, w1p, w2p, w3p, scalars8, dtype=None):
     """Whole 'same' Fixup block in one launch (x NHWC [B,H,W,C]); scalars8 = (b1a,b1b,b2a,b2b,b3a,b3b,b4,scale)."""
     _need_gpu(x, w1p, w2p, w3p)
     x = x.contiguous()
     B, H, W, C = x.shape
     y = torch.empty_like(x)
     sc = (ctypes.c_float * 8)(*[float(v) for v in scalars8])
-    L.check(L.lib().vqae_fixup_same_block_f32(_p(x), _p(y), _p(w1p), _p(w2p), _p(w3p), B, H, W, C, sc, _stream()))
+    L.check(L.lib().vqae_fixup_same_block_f32(_p(x), _p(y), _p(w1p), _p(w2p), _p(w3p), B, H, W, C, sc,
+                                              L.dtype_code(dtype), _stream()))
     return y
 
 
-def conv3x3_direct(x, w, bias, x_u8=None, mean255=None, inv_std255=None):
+def conv3x3_direct(x, w, bias, x_u8=None, mean255=None, inv_std255=None, dtype=None):
     """Stem conv (3x3, zero pad, bias); x NHWC fp32 or x_u8 NHWC uint8 (normalised on device)."""
     src = x if x_u8 is None else x_u8
     _need_gpu(src, w, bias)
@@ -117,7 +121,7 @@ def conv3x3_direct(x, w, bias, x_u8=None, mean255=None, inv_std255=None):
     s = (ctypes.c_float * 3)(*inv_std255) if inv_std255 is not None else None
     L.check(L.lib().vqae_conv3x3_direct_f32(_p(x) if x_u8 is None else None, _p(x_u8) if x_u8 is not None else None,
                                             m, s, _p(w.contiguous()), _p(bias.contiguous()), B, H, W, cin, cout,
-                                            _p(y), _stream()))
+                                            _p(y), L.dtype_code(dtype), _stream()))
     return y
 
 

@@ -39,6 +39,12 @@ typedef enum vqae_status {
 } vqae_status;
 
 enum { VQAE_LAYOUT_NHWC = 0, VQAE_LAYOUT_NCHW = 1 };
+/* Compute precision of the convolutions, with torch.autocast semantics (the reference's extraction runs
+ * `with torch.autocast('cuda')`, scripts/extract_embeddings/extract_embeddings.py:124-125): conv inputs,
+ * weights and conv biases are rounded (RNE) to the 16-bit type, products are accumulated in fp32, the conv
+ * output is rounded to the 16-bit type; everything else (Fixup scalar biases/scale, ELU, residual adds,
+ * bicubic, the p=4 distance, losses) stays fp32, exactly as type promotion leaves it in the reference. */
+enum { VQAE_DT_F32 = 0, VQAE_DT_BF16 = 1, VQAE_DT_F16 = 2 };
 enum { VQAE_IDX_I64 = 0, VQAE_IDX_U8 = 1, VQAE_IDX_U16 = 2, VQAE_IDX_I32 = 3 };
 
 const char* vqae_last_error(void);
@@ -111,11 +117,13 @@ typedef struct vqae_conv_args {
     int pre_mode;
     float pre_a, pre_b;
     /* epilogue, in the reference's rounding order (conv_block.py:208-214):
-     *   t = acc; if (has_scale) t = t * scale + bias_s;  else if (has_bias_s) t = t + bias_s;
-     *   if (bias_vec) t = t + bias_vec[c];   if (residual) t = t + residual[m][c];
+     *   t = acc; if (bias_vec) t = t + bias_vec[c];  (the conv's own bias)   t = round_dtype(t);
+     *   if (has_scale) t = t * scale + bias_s;  else if (has_bias_s) t = t + bias_s;
+     *   if (residual) t = t + residual[m][c];
      *   if (has_act) t = ELU(t + act_a) + act_b;   (the NEXT conv's pre-op, fused here) */
     int has_scale, has_bias_s, has_act;
     float scale, bias_s, act_a, act_b;
+    int dtype;            /* VQAE_DT_*: autocast rounding of operands (after the pre-op) and of acc (+ bias_vec) */
 } vqae_conv_args;
 
 /* x_dev [B][H][W][cin], w_packed_dev from vqae_conv_pack_weight_f32, bias_vec_dev [cout] or NULL,
@@ -132,7 +140,9 @@ int vqae_conv2d_f32(const vqae_conv_args* a, const float* x_dev, const float* w_
 int vqae_fixup_same_supported(int c, int h, int w);
 int vqae_fixup_same_block_f32(const float* x_dev, float* y_dev, const float* w1_packed_dev, const float* w2_packed_dev,
                               const float* w3_packed_dev, int batch, int h, int w, int c, const float* scalars8,
-                              void* stream);
+                              int dtype /* VQAE_DT_* */, void* stream);
+/* Round a device fp32 array in place to bf16/f16-representable values (autocast weight cast). */
+int vqae_round_inplace_f32(float* x_dev, int64_t n, int dtype, void* stream);
 
 /* Direct (VALU) 3x3 / stride 1 / zero-pad conv with per-channel bias for tiny channel counts:
  * the stems `in_stem` (3 -> C0, model.py:198) and `out_stem` (C0 -> 3, model.py:291).
@@ -141,7 +151,7 @@ int vqae_fixup_same_block_f32(const float* x_dev, float* y_dev, const float* w1_
  * ((u - mean255[c]) * inv_std255[c], albumentations Normalize, camelyon16_transforms.yaml:15-23). */
 int vqae_conv3x3_direct_f32(const float* x_dev, const uint8_t* x_u8_dev, const float* mean255, const float* inv_std255,
                             const float* w_oihw_dev, const float* bias_dev, int batch, int h, int w, int cin,
-                            int cout, float* y_dev, void* stream);
+                            int cout, float* y_dev, int dtype /* VQAE_DT_* */, void* stream);
 
 /* y = bicubic_x2(x + pre_bias), A = -0.75, align_corners = False, index-clamped borders
  * (nn.Upsample(mode='bicubic', scale_factor=2), layers/conv.py:8).  x [B][H][W][C] -> y [B][2H][2W][C]. */
@@ -176,6 +186,7 @@ typedef struct vqae_config {
     int num_embeddings;   /* layers/vq/ema_vq.yaml:2 */
     int projection_dim;   /* 0: EMAVectorQuantizer; >0: ProjectedEMAVectorQuantizer2d (vq.py:157-192) */
     float commitment_cost;
+    int compute_dtype;    /* VQAE_DT_F32 (default) or autocast bf16 / f16 */
 } vqae_config;
 
 /* One named fp32 host tensor, named as in the reference's state_dict, e.g.

@@ -147,6 +147,34 @@ def gen_model(name, batch, size, full_taps):
     save(f"model_{name}", **arrays)
 
 
+# ---------------------------------------------------------------- G7: autocast (BASELINE configs #3 / #4)
+def gen_model_autocast(name, batch, size, dtype, tag):
+    """The reference under torch.autocast('cpu', dtype) -- what `with torch.autocast('cuda')` does to the
+    encoder in the extraction script (extract_embeddings.py:124-125), here for the whole VQAE.forward."""
+    spec = O.SPECS[name]
+    p = O.make_params(spec, 0)
+    x = O.make_patches(batch, size, 0)
+    p = O.calibrate_codebook(O.make_patches(2, size, 99), p, spec)
+    model = S.build_reference_model(spec, p)
+    t = time.time()
+    with torch.autocast("cpu", dtype=dtype):
+        out, losses = model(x)
+        (q,), (idx,), (loss,) = model.encoder(x)
+    t_ref = time.time() - t
+    (_,), (idx32,), _ = model.encoder(x)
+    ot = {}
+    oout, olosses = O.vqae_forward(x, p, spec, ot, dtype=dtype)
+    assert torch.equal(ot["idx"], idx) and torch.equal(oout, out), "oracle autocast path deviates from the reference"
+    agree32 = (idx == idx32).float().mean().item()
+    print(f"  {name} {tag}: reference {t_ref:.1f}s, out dtype {out.dtype}, oracle identical; "
+          f"index agreement with the fp32 reference {agree32 * 100:.2f}%")
+    save(f"model_{name}_{tag}", spec=np.array(repr(spec.to_dict())), batch=batch, size=size,
+         idx=idx.numpy().astype(np.uint16), idx_fp32=idx32.numpy().astype(np.uint16),
+         loss=np.float32(float(loss)), out_sample=out.float()[:, :, ::16, ::16].numpy(),
+         out_mean=out.float().mean(dim=(1, 2, 3)).numpy(), out_std=out.float().std(dim=(1, 2, 3)).numpy(),
+         q_sample=q.float()[:, ::8, ::4, ::4].numpy(), embed=p["encoder.vq_layers.0.embed"].numpy())
+
+
 # ---------------------------------------------------------------- G5: driver
 def gen_driver():
     S.install()
@@ -250,7 +278,7 @@ def gen_ema():
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="vq,tiny,tinyP,B,A,C,driver,ema")
+    ap.add_argument("--only", default="vq,tiny,tinyP,B,A,C,driver,ema,autocast")
     args = ap.parse_args()
     todo = args.only.split(",")
     torch.manual_seed(0)
@@ -266,6 +294,13 @@ if __name__ == "__main__":
         print("G4 cfg A b=2"); gen_model("A", 2, 512, False)
     if "C" in todo:
         print("G4 cfg C b=1"); gen_model("C", 1, 256, False)
+    if "autocast" in todo:
+        print("G7 autocast")
+        gen_model_autocast("tinyP", 2, 32, torch.bfloat16, "bf16")
+        gen_model_autocast("tiny", 2, 32, torch.float16, "f16")
+        gen_model_autocast("B", 2, 256, torch.bfloat16, "bf16")
+        gen_model_autocast("A", 2, 512, torch.bfloat16, "bf16")      # BASELINE config #3
+        gen_model_autocast("C", 1, 256, torch.float16, "f16")        # BASELINE config #4
     if "driver" in todo:
         print("G5 driver"); gen_driver()
     if "ema" in todo:

@@ -83,9 +83,11 @@ __device__ __forceinline__ float elu1(float v) {
 // The 128 x C activation tile goes accumulator -> LDS ([128][C + 4], over the dead staging buffers) ->
 // A fragments; the C x C weight matrices (<= 64 KB) are read as B fragments straight from L2.  This removes the
 // two HBM-bound 1x1 launches per trunk block (4 of the 7 activation passes) with no halo recompute.
-template <int NT, int KC, int PRE, bool PADZ, int TAIL>
+template <int NT, int KC, int PRE, bool PADZ, int TAIL, bool R16>
 __global__ __launch_bounds__(256, 2)
 void conv_mfma_kernel(const ConvK p) {
+    // R16: autocast rounding points compiled in (p.dt selects bf16 / f16); the fp32 build has none
+    auto rnd = [&](float v) { return R16 ? vqae::round_dt(v, p.dt) : v; };
     constexpr int LDR = KC + 4;                      // LDS row stride (floats)
     constexpr int WN = (NT == 128) ? 2 : 1;          // waves along N
     constexpr int WM = 4 / WN;                       // waves along M
@@ -213,9 +215,9 @@ void conv_mfma_kernel(const ConvK p) {
                 }
             }
             if (PADZ) { if ((raz >> i) & 1u) v = (f32x4)(0.f); }
-            if (p.dt) {
+            if (R16) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = vqae::round_dt(v[e], p.dt);       // cast at the conv input
+                for (int e = 0; e < 4; ++e) v[e] = rnd(v[e]);                        // cast at the conv input
             }
             *reinterpret_cast<f32x4*>(As + a_wr[i]) = v;
         }
@@ -374,7 +376,7 @@ void conv_mfma_kernel(const ConvK p) {
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)           // conv2 output cast, fp32 activation, conv3 input cast
-                    acc[mi][ni][r] = vqae::round_dt(elu1(vqae::round_dt(acc[mi][ni][r], p.dt) + p.act_a) + p.act_b, p.dt);
+                    acc[mi][ni][r] = rnd(elu1(rnd(acc[mi][ni][r]) + p.act_a) + p.act_b);
         __syncthreads();                                    // every wave is done with the last K-step's tiles
         acc_to_lds();
         __syncthreads();
@@ -396,11 +398,11 @@ void conv_mfma_kernel(const ConvK p) {
                     res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, base + ((r & 3) + 8 * (r >> 2)) * (CC * 4), 0, 0));
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float t = vqae::round_dt(acc[mi][ni][r], p.dt) * p.t_scale;
+                    float t = rnd(acc[mi][ni][r]) * p.t_scale;
                     t = t + p.t_b4;
                     t = t + res[r];
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), o_rsrc, base + ((r & 3) + 8 * (r >> 2)) * (CC * 4), 0, 0);
-                    if (TAIL == 2) acc[mi][ni][r] = vqae::round_dt(elu1(t + p.n_b1a) + p.n_b1b, p.dt);     // next block's conv1 pre-op
+                    if (TAIL == 2) acc[mi][ni][r] = rnd(elu1(t + p.n_b1a) + p.n_b1b);     // next block's conv1 pre-op
                 }
             }
         if constexpr (TAIL == 2) {
@@ -417,7 +419,7 @@ void conv_mfma_kernel(const ConvK p) {
                     const unsigned base = (unsigned)((wm * MI * 32 + mi * 32 + 4 * hh) * (CC * 4) + (wn * NI * 32 + ni * 32 + li) * 4);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float t = elu1(vqae::round_dt(acc[mi][ni][r], p.dt) + p.n_b2a) + p.n_b2b;
+                        const float t = elu1(rnd(acc[mi][ni][r]) + p.n_b2a) + p.n_b2b;
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), t_rsrc, base + ((r & 3) + 8 * (r >> 2)) * (CC * 4), 0, 0);
                     }
                 }
@@ -457,7 +459,7 @@ void conv_mfma_kernel(const ConvK p) {
             for (int r = 0; r < 16; ++r) {
                 float t = acc[mi][ni][r];
                 if (p.bias_vec) t = t + bv;                 // the conv's own bias is part of the (16-bit) conv output
-                t = vqae::round_dt(t, p.dt);
+                t = rnd(t);
                 if (p.has_scale) { t = t * p.scale; t = t + p.bias_s; }
                 else if (p.has_bias_s) { t = t + p.bias_s; }
                 if (p.residual) t = t + res[r];
@@ -478,24 +480,30 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int cout, int ci
     out[i] = (n < cout) ? w[((int64_t)n * cin + ci) * ks * ks + tap] : 0.f;
 }
 
-template <int NT, int KC, int PRE, bool PADZ, int TAIL = 0>
-int launch(const ConvK& k, hipStream_t stream) {
+template <int NT, int KC, int PRE, bool PADZ, int TAIL, bool R16>
+int launch_r(const ConvK& k, hipStream_t stream) {
     const int npad = (int)vqae::round_up(k.Cout, 32);
     dim3 grid((unsigned)vqae::ceil_div(k.M, 128), (unsigned)vqae::ceil_div(npad, NT));
     constexpr int lds_bytes = 2 * (128 + NT) * (KC + 4) * (int)sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)conv_mfma_kernel<NT, KC, PRE, PADZ, TAIL>,
+        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)conv_mfma_kernel<NT, KC, PRE, PADZ, TAIL, R16>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         attr_set = true;
     }
     const int cls = (NT == 128 && KC == 32 && k.Cin >= 128) ? (k.ks == 3 ? vqae::PROF_CONV3X3_TRUNK : (k.ks == 1 ? vqae::PROF_CONV1X1_TRUNK : 0)) : 0;
     const double flops = 2.0 * k.M * (double)k.Cout * ((double)k.Ktot + (TAIL >= 1 ? (double)k.Cout : 0.0) + (TAIL == 2 ? (double)k.Cout : 0.0));
     vqae::ProfScope prof(cls, stream, flops);
-    conv_mfma_kernel<NT, KC, PRE, PADZ, TAIL><<<grid, 256, lds_bytes, stream>>>(k);
+    conv_mfma_kernel<NT, KC, PRE, PADZ, TAIL, R16><<<grid, 256, lds_bytes, stream>>>(k);
     prof.done();
     VQAE_LAUNCH_CHECK();
     return VQAE_OK;
+}
+
+template <int NT, int KC, int PRE, bool PADZ, int TAIL = 0>
+int launch(const ConvK& k, hipStream_t stream) {
+    if (k.dt != VQAE_DT_F32) return launch_r<NT, KC, PRE, PADZ, TAIL, true>(k, stream);
+    return launch_r<NT, KC, PRE, PADZ, TAIL, false>(k, stream);
 }
 
 template <int NT, int KC>

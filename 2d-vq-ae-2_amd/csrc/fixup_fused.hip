@@ -15,6 +15,9 @@
 
 namespace {
 
+// autocast rounding point: compiled in only for the 16-bit instantiations (p.dt picks bf16 / f16)
+#define RND(v) (R16 ? vqae::round_dt((v), p.dt) : (v))
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -59,7 +62,7 @@ struct FusedCfg {
     static constexpr int LDS_FLOATS = 2 * 32 * LDT + 32 * LDW2 + HPP * LDT;
 };
 
-template <int C, int TH>
+template <int C, int TH, bool R16>
 __global__ __launch_bounds__(256, (C <= 16 ? 3 : 2))
 void fixup_same_small_kernel(const FusedP p) {
     using K = FusedCfg<C, TH>;
@@ -129,7 +132,7 @@ void fixup_same_small_kernel(const FusedP p) {
                 for (int u = 0; u < C / 8; ++u) {
                     f32x4 v = a[u] + p.b1a;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = vqae::round_dt(elu1f(v[e]) + p.b1b, p.dt);
+                    for (int e = 0; e < 4; ++e) v[e] = RND(elu1f(v[e]) + p.b1b);
                     const f32x4 bw = *reinterpret_cast<const f32x4*>(w1f + 8 * u);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[r], bw[r], acc, 0, 0, 0);
@@ -138,7 +141,7 @@ void fixup_same_small_kernel(const FusedP p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                        T1[(32 * g + row) * LDT + li] = vqae::round_dt(elu1f(vqae::round_dt(acc[r], p.dt) + p.b2a) + p.b2b, p.dt);
+                        T1[(32 * g + row) * LDT + li] = RND(elu1f(RND(acc[r]) + p.b2a) + p.b2b);
                     }
                 }
             }
@@ -175,7 +178,7 @@ void fixup_same_small_kernel(const FusedP p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    T1[(ry * 32 + row) * LDT + li] = vqae::round_dt(elu1f(vqae::round_dt(acc2[mt][r], p.dt) + p.b3a) + p.b3b, p.dt);   // t2 over t1
+                    T1[(ry * 32 + row) * LDT + li] = RND(elu1f(RND(acc2[mt][r]) + p.b3a) + p.b3b);   // t2 over t1
                 }
             }
         }
@@ -202,7 +205,7 @@ void fixup_same_small_kernel(const FusedP p) {
                 for (int r = 0; r < 16; ++r) res[r] = p.x[rowbase + ((r & 3) + 8 * (r >> 2) + 4 * h) * C];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float tv = vqae::round_dt(acc3[r], p.dt) * p.scale;
+                    float tv = RND(acc3[r]) * p.scale;
                     tv = tv + p.b4;
                     tv = tv + res[r];
                     p.y[rowbase + ((r & 3) + 8 * (r >> 2) + 4 * h) * C] = tv;
@@ -213,13 +216,13 @@ void fixup_same_small_kernel(const FusedP p) {
     }
 }
 
-template <int C, int TH>
-int launch_fused(FusedP& p, hipStream_t stream) {
+template <int C, int TH, bool R16>
+int launch_fused_r(FusedP& p, hipStream_t stream) {
     using K = FusedCfg<C, TH>;
     constexpr int lds_bytes = K::LDS_FLOATS * (int)sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)fixup_same_small_kernel<C, TH>,
+        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)fixup_same_small_kernel<C, TH, R16>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         attr_set = true;
     }
@@ -229,7 +232,7 @@ int launch_fused(FusedP& p, hipStream_t stream) {
     const int per_cu = (C <= 16 ? 3 : 2);
     int grid = 256 * per_cu;
     if (grid > p.n_tiles) grid = p.n_tiles;
-    fixup_same_small_kernel<C, TH><<<grid, 256, lds_bytes, stream>>>(p);
+    fixup_same_small_kernel<C, TH, R16><<<grid, 256, lds_bytes, stream>>>(p);
     VQAE_LAUNCH_CHECK();
     return VQAE_OK;
 }
@@ -247,7 +250,7 @@ template <int C> struct KVec;
 template <> struct KVec<16> { typedef f32x4 type; };
 template <> struct KVec<8> { typedef f32x2 type; };
 
-template <int C, int TH>
+template <int C, int TH, bool R16>
 __global__ __launch_bounds__(256, 3)
 void fixup_same_tiny_kernel(const FusedP p) {
     using K = FusedCfg<C, TH>;
@@ -315,13 +318,13 @@ void fixup_same_tiny_kernel(const FusedP p) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int k = 0; k < KQ; ++k) {
-                    const float av = vqae::round_dt(elu1f(v[k]) + p.b1b, p.dt);
+                    const float av = RND(elu1f(v[k]) + p.b1b);
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w1v[k], acc, 0, 0, 0);
                 }
                 if (n_ok) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        T1[(16 * g + 4 * q + r) * LDT + li] = vqae::round_dt(elu1f(vqae::round_dt(acc[r], p.dt) + p.b2a) + p.b2b, p.dt);
+                        T1[(16 * g + 4 * q + r) * LDT + li] = RND(elu1f(RND(acc[r]) + p.b2a) + p.b2b);
                 }
             }
         }
@@ -358,7 +361,7 @@ void fixup_same_tiny_kernel(const FusedP p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         T1[((wave + 4 * mt) * 32 + 16 * hf + 4 * q + r) * LDT + li] =
-                            vqae::round_dt(elu1f(vqae::round_dt(acc2[mt][hf][r], p.dt) + p.b3a) + p.b3b, p.dt);
+                            RND(elu1f(RND(acc2[mt][hf][r]) + p.b3a) + p.b3b);
         }
         __syncthreads();
 
@@ -377,7 +380,7 @@ void fixup_same_tiny_kernel(const FusedP p) {
                     const int64_t base = (((int64_t)b * p.H + ty0 + ry) * p.W + tx0 + 16 * hf + 4 * q) * C + li;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float tv = vqae::round_dt(acc3[r], p.dt) * p.scale;
+                        float tv = RND(acc3[r]) * p.scale;
                         tv = tv + p.b4;
                         tv = tv + p.x[base + r * C];
                         p.y[base + r * C] = tv;
@@ -389,13 +392,13 @@ void fixup_same_tiny_kernel(const FusedP p) {
     }
 }
 
-template <int C, int TH>
-int launch_tiny(FusedP& p, hipStream_t stream) {
+template <int C, int TH, bool R16>
+int launch_tiny_r(FusedP& p, hipStream_t stream) {
     using K = FusedCfg<C, TH>;
     constexpr int lds_bytes = K::LDS_FLOATS * (int)sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)fixup_same_tiny_kernel<C, TH>,
+        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)fixup_same_tiny_kernel<C, TH, R16>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         attr_set = true;
     }
@@ -404,10 +407,20 @@ int launch_tiny(FusedP& p, hipStream_t stream) {
     p.n_tiles = p.B * p.tiles_x * p.tiles_y;
     int grid = 256 * 3;
     if (grid > p.n_tiles) grid = p.n_tiles;
-    fixup_same_tiny_kernel<C, TH><<<grid, 256, lds_bytes, stream>>>(p);
+    fixup_same_tiny_kernel<C, TH, R16><<<grid, 256, lds_bytes, stream>>>(p);
     VQAE_LAUNCH_CHECK();
     return VQAE_OK;
 }
+
+template <int C, int TH>
+int launch_fused(FusedP& p, hipStream_t stream) {
+    return p.dt ? launch_fused_r<C, TH, true>(p, stream) : launch_fused_r<C, TH, false>(p, stream);
+}
+template <int C, int TH>
+int launch_tiny(FusedP& p, hipStream_t stream) {
+    return p.dt ? launch_tiny_r<C, TH, true>(p, stream) : launch_tiny_r<C, TH, false>(p, stream);
+}
+#undef RND
 
 }  // namespace
 

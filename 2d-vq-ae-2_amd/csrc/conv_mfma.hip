@@ -43,6 +43,7 @@ struct ConvK {
     float* y2;                           // [M][128]: next block's t1 (TAIL == 2)
     float t_scale, t_b4, n_b1a, n_b1b, n_b2a, n_b2b;
     int dt;                              // VQAE_DT_*: autocast rounding points
+    int m16;                             // 16-bit MFMA engine (dt != 0, cin % 32 == 0, no zero padding)
 };
 
 // ELU(alpha = 1) = v > 0 ? v : expm1(v), branch-free so the Fixup pre-op / epilogue can be scheduled
@@ -77,18 +78,80 @@ __device__ __forceinline__ float elu1(float v) {
 //     base VGPR + immediate;
 //   * the epilogue addresses through buffer descriptors (hardware range check drops the M tail).
 // ------------------------------------------------------------------------------------------------
+
+// ---- matrix-engine policy: exact-fp32 MFMA (32x32x2, 4 per 8-deep k-slice) or 16-bit MFMA (32x32x16, one per
+// 16-deep k-slice; autocast modes only).  Both use the same 32x32 C/D layout and the same LDS image idea:
+// [row][KC + PAD] elements, lane (i = l&31, h = l>>5) reads SK/2 consecutive k at SK*u + (SK/2)*h.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+template <int DT, bool M16> struct MP {               // fp32 engine (any DT: DT only adds rounding points)
+    using elem = float;
+    using frag = f32x4;
+    static constexpr int SK = 8, PAD = 4;
+    static __device__ __forceinline__ void mma(f32x16& acc, const frag& a, const frag& b) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b[r], acc, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void store4(elem* d, f32x4 v) { *reinterpret_cast<f32x4*>(d) = v; }
+    static __device__ __forceinline__ frag load_b(const float* q) { return *reinterpret_cast<const f32x4*>(q); }
+    static __device__ __forceinline__ elem cvt(float v) { return v; }
+};
+template <> struct MP<VQAE_DT_BF16, true> {
+    using elem = __bf16;
+    using frag = bf16x8;
+    static constexpr int SK = 16, PAD = 8;
+    static __device__ __forceinline__ void mma(f32x16& acc, const frag& a, const frag& b) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void store4(elem* d, f32x4 v) { *reinterpret_cast<bf16x4*>(d) = __builtin_convertvector(v, bf16x4); }
+    static __device__ __forceinline__ frag load_b(const float* q) {
+        const bf16x4 lo = __builtin_convertvector(*reinterpret_cast<const f32x4*>(q), bf16x4);
+        const bf16x4 hi = __builtin_convertvector(*reinterpret_cast<const f32x4*>(q + 4), bf16x4);
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+    static __device__ __forceinline__ elem cvt(float v) { return (__bf16)v; }
+};
+template <> struct MP<VQAE_DT_F16, true> {
+    using elem = _Float16;
+    using frag = f16x8;
+    static constexpr int SK = 16, PAD = 8;
+    static __device__ __forceinline__ void mma(f32x16& acc, const frag& a, const frag& b) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void store4(elem* d, f32x4 v) { *reinterpret_cast<f16x4*>(d) = __builtin_convertvector(v, f16x4); }
+    static __device__ __forceinline__ frag load_b(const float* q) {
+        const f16x4 lo = __builtin_convertvector(*reinterpret_cast<const f32x4*>(q), f16x4);
+        const f16x4 hi = __builtin_convertvector(*reinterpret_cast<const f32x4*>(q + 4), f16x4);
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+    static __device__ __forceinline__ elem cvt(float v) { return (_Float16)v; }
+};
+template <int DT> __device__ __forceinline__ float round_ct(float v) {
+    if (DT == VQAE_DT_BF16) return (float)(__bf16)v;
+    if (DT == VQAE_DT_F16) return (float)(_Float16)v;
+    return v;
+}
+
 // TAIL (KC = 32, Cin = Cout = NT in {64, 128}): after the 3x3 conv2 of a trunk Fixup block the same
 // workgroup also runs   TAIL >= 1: conv3 (1x1) + scale/bias4 + residual  -> block output (in place over x)
 //                       TAIL == 2: conv1 (1x1) of the NEXT block on that output tile -> its t1.
 // The 128 x C activation tile goes accumulator -> LDS ([128][C + 4], over the dead staging buffers) ->
 // A fragments; the C x C weight matrices (<= 64 KB) are read as B fragments straight from L2.  This removes the
 // two HBM-bound 1x1 launches per trunk block (4 of the 7 activation passes) with no halo recompute.
-template <int NT, int KC, int PRE, bool PADZ, int TAIL, bool R16>
+template <int NT, int KC, int PRE, bool PADZ, int TAIL, int DT, bool M16>
 __global__ __launch_bounds__(256, 2)
 void conv_mfma_kernel(const ConvK p) {
-    // R16: autocast rounding points compiled in (p.dt selects bf16 / f16); the fp32 build has none
-    auto rnd = [&](float v) { return R16 ? vqae::round_dt(v, p.dt) : v; };
-    constexpr int LDR = KC + 4;                      // LDS row stride (floats)
+    // DT: autocast rounding points compiled in (the fp32 build has none); M16: 16-bit MFMA engine
+    using P = MP<DT, M16>;
+    using elem = typename P::elem;
+    using frag = typename P::frag;
+    constexpr bool R16 = DT != VQAE_DT_F32;
+    auto rnd = [&](float v) { return round_ct<DT>(v); };
+    constexpr int SK = P::SK;                        // k-slice per fragment read
+    constexpr int LDR = KC + P::PAD;                 // LDS row stride (elements)
     constexpr int WN = (NT == 128) ? 2 : 1;          // waves along N
     constexpr int WM = 4 / WN;                       // waves along M
     constexpr int MI = 128 / (WM * 32);              // 32-row MFMA tiles per wave along M
@@ -97,12 +160,12 @@ void conv_mfma_kernel(const ConvK p) {
     constexpr int B_F4 = NT * KC / 4;                // float4 in the B tile
     constexpr int B_PT = (B_F4 + 255) / 256;
     constexpr int C4 = KC / 4;                       // float4 per tile row
-    constexpr int A_BUF = 128 * LDR;                 // floats per A buffer
+    constexpr int A_BUF = 128 * LDR;                 // elements per A buffer
     constexpr int B_BUF = NT * LDR;
 
     extern __shared__ __attribute__((aligned(16))) float lds[];   // A0 A1 B0 B1
-    float* const Abuf0 = lds;
-    float* const Bbuf0 = lds + 2 * A_BUF;
+    elem* const Abuf0 = reinterpret_cast<elem*>(lds);
+    elem* const Bbuf0 = Abuf0 + 2 * A_BUF;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -203,7 +266,7 @@ void conv_mfma_kernel(const ConvK p) {
             if (nx_tap < p.ks * p.ks) set_tap(nx_tap);
         }
     };
-    auto stage = [&](float* As, float* Bs) {         // registers -> LDS (+ Fixup pre-op, zero padding)
+    auto stage = [&](elem* As, elem* Bs) {           // registers -> LDS (+ Fixup pre-op, zero padding)
 #pragma unroll
         for (int i = 0; i < A_PT; ++i) {
             f32x4 v = ra[i];
@@ -219,11 +282,11 @@ void conv_mfma_kernel(const ConvK p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = rnd(v[e]);                        // cast at the conv input
             }
-            *reinterpret_cast<f32x4*>(As + a_wr[i]) = v;
+            P::store4(As + a_wr[i], v);
         }
 #pragma unroll
         for (int i = 0; i < B_PT; ++i)
-            if (B_F4 % 256 == 0 || tid + i * 256 < B_F4) *reinterpret_cast<f32x4*>(Bs + b_wr[i]) = rb[i];
+            if (B_F4 % 256 == 0 || tid + i * 256 < B_F4) P::store4(Bs + b_wr[i], rb[i]);
     };
 
     f32x16 acc[MI][NI];
@@ -234,45 +297,52 @@ void conv_mfma_kernel(const ConvK p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    const float* const a_frag = Abuf0 + (wm * MI * 32 + (lane & 31)) * LDR + 4 * (lane >> 5);
-    const float* const b_frag = Bbuf0 + (wn * NI * 32 + (lane & 31)) * LDR + 4 * (lane >> 5);
-    auto compute = [&](const float* As, const float* Bs) {
-        // fragment reads are software-pipelined one 8-deep k-slice ahead of the MFMAs that use them
-        f32x4 a[2][MI], b[2][NI];
+    const elem* const a_frag = Abuf0 + (wm * MI * 32 + (lane & 31)) * LDR + (SK / 2) * (lane >> 5);
+    const elem* const b_frag = Bbuf0 + (wn * NI * 32 + (lane & 31)) * LDR + (SK / 2) * (lane >> 5);
+    auto compute = [&](const elem* As, const elem* Bs) {
+        // fragment reads are software-pipelined one k-slice ahead of the MFMAs that use them
+        frag a[2][MI], b[2][NI];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) a[0][mi] = *reinterpret_cast<const f32x4*>(As + mi * 32 * LDR);
+        for (int mi = 0; mi < MI; ++mi) a[0][mi] = *reinterpret_cast<const frag*>(As + mi * 32 * LDR);
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) b[0][ni] = *reinterpret_cast<const f32x4*>(Bs + ni * 32 * LDR);
+        for (int ni = 0; ni < NI; ++ni) b[0][ni] = *reinterpret_cast<const frag*>(Bs + ni * 32 * LDR);
 #pragma unroll
-        for (int u = 0; u < KC / 8; ++u) {
-            if (u + 1 < KC / 8) {
+        for (int u = 0; u < KC / SK; ++u) {
+            if (u + 1 < KC / SK) {
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
-                    a[(u + 1) & 1][mi] = *reinterpret_cast<const f32x4*>(As + mi * 32 * LDR + 8 * (u + 1));
+                    a[(u + 1) & 1][mi] = *reinterpret_cast<const frag*>(As + mi * 32 * LDR + SK * (u + 1));
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
-                    b[(u + 1) & 1][ni] = *reinterpret_cast<const f32x4*>(Bs + ni * 32 * LDR + 8 * (u + 1));
+                    b[(u + 1) & 1][ni] = *reinterpret_cast<const frag*>(Bs + ni * 32 * LDR + SK * (u + 1));
             }
+            if constexpr (!M16) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u & 1][mi][r], b[u & 1][ni][r], acc[mi][ni], 0, 0, 0);
+            } else {
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u & 1][mi][r], b[u & 1][ni][r], acc[mi][ni], 0, 0, 0);
+                    for (int ni = 0; ni < NI; ++ni) P::mma(acc[mi][ni], a[u & 1][mi], b[u & 1][ni]);
+            }
         }
     };
 
     // One K-step as a single scheduling region: the gather's loads are issued between the first MFMAs,
     // the LDS stores of the gathered tile between the last ones, so the matrix pipe (64 cycles per
     // 32x32x2 MFMA) never drains while this wave issues memory instructions.
-    constexpr int N_MFMA = MI * NI * (KC / 2);       // MFMAs per wave per step
+    constexpr int N_MFMA = M16 ? MI * NI * (KC / 16) : MI * NI * (KC / 2);   // MFMAs per wave per step
     constexpr int N_LD = A_PT + B_PT;                // global loads / LDS stores per thread per step
-    auto step = [&](const float* As, const float* Bs, float* Asn, float* Bsn) {
+    auto step = [&](const elem* As, const elem* Bs, elem* Asn, elem* Bsn) {
         gather();
         compute(As, Bs);
         stage(Asn, Bsn);
-        if (N_MFMA >= 4 * N_LD) {
+        if (!M16 && N_MFMA >= 4 * N_LD) {
 #pragma unroll
             for (int i = 0; i < N_LD; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
@@ -313,10 +383,10 @@ void conv_mfma_kernel(const ConvK p) {
     }
 
     if constexpr (TAIL > 0) {
-        static_assert((NT == 128 || NT == 64) && KC == 32, "fused tail: the N tile must cover all C = NT channels");
+        static_assert(NT == 128 || NT == 64, "fused tail: the N tile must cover all C = NT channels");
         constexpr int CC = NT;                              // channels of the block
-        constexpr int LDT = CC + 4;
-        float* const T = lds;                               // [128][CC + 4], aliases the staging buffers
+        constexpr int LDT = CC + P::PAD;
+        elem* const T = reinterpret_cast<elem*>(lds);       // [128][CC + PAD], aliases the staging buffers
         const int li = lane & 31, hh = lane >> 5;
         const int rows_valid_t = (p.M - m0 < 128) ? (p.M - m0) : 128;
         const unsigned range_t = (unsigned)rows_valid_t * (unsigned)CC * 4u;
@@ -328,7 +398,7 @@ void conv_mfma_kernel(const ConvK p) {
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        T[(wm * MI * 32 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * LDT + wn * NI * 32 + ni * 32 + li] = acc[mi][ni][r];
+                        T[(wm * MI * 32 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * LDT + wn * NI * 32 + ni * 32 + li] = P::cvt(acc[mi][ni][r]);
         };
         auto gemm_tail = [&](const float* __restrict__ wsrc) {   // acc = T (128 x CC) x wsrc^T, K = CC
 #pragma unroll
@@ -337,34 +407,42 @@ void conv_mfma_kernel(const ConvK p) {
                 for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-            const float* af = T + (wm * MI * 32 + li) * LDT + 4 * hh;
-            const float* bf = wsrc + (wn * NI * 32 + li) * CC + 4 * hh;
-            f32x4 bq[2][4][NI];                             // B fragments, 4 k-slices per group, 2 groups in flight
+            const elem* af = T + (wm * MI * 32 + li) * LDT + (SK / 2) * hh;
+            const float* bf = wsrc + (wn * NI * 32 + li) * CC + (SK / 2) * hh;
+            constexpr int NG = CC / (4 * SK);               // groups of 4 k-slices
+            frag bq[2][4][NI];                              // B fragments, 4 k-slices per group, 2 groups in flight
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) bq[0][u][ni] = *reinterpret_cast<const f32x4*>(bf + ni * 32 * CC + 8 * u);
+                for (int ni = 0; ni < NI; ++ni) bq[0][u][ni] = P::load_b(bf + ni * 32 * CC + SK * u);
 #pragma unroll
-            for (int ug = 0; ug < CC / 32; ++ug) {
-                if (ug + 1 < CC / 32) {
+            for (int ug = 0; ug < NG; ++ug) {
+                if (ug + 1 < NG) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
 #pragma unroll
                         for (int ni = 0; ni < NI; ++ni)
-                            bq[(ug + 1) & 1][u][ni] = *reinterpret_cast<const f32x4*>(bf + ni * 32 * CC + 8 * (4 * (ug + 1) + u));
+                            bq[(ug + 1) & 1][u][ni] = P::load_b(bf + ni * 32 * CC + SK * (4 * (ug + 1) + u));
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    f32x4 a[MI];
+                    frag a[MI];
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(af + mi * 32 * LDT + 8 * (4 * ug + u));
+                    for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const frag*>(af + mi * 32 * LDT + SK * (4 * ug + u));
+                    if constexpr (!M16) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                                for (int ni = 0; ni < NI; ++ni)
+                                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][r], bq[ug & 1][u][ni][r], acc[mi][ni], 0, 0, 0);
+                    } else {
 #pragma unroll
                         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                            for (int ni = 0; ni < NI; ++ni)
-                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][r], bq[ug & 1][u][ni][r], acc[mi][ni], 0, 0, 0);
+                            for (int ni = 0; ni < NI; ++ni) P::mma(acc[mi][ni], a[mi], bq[ug & 1][u][ni]);
+                    }
                 }
             }
         };
@@ -480,21 +558,22 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int cout, int ci
     out[i] = (n < cout) ? w[((int64_t)n * cin + ci) * ks * ks + tap] : 0.f;
 }
 
-template <int NT, int KC, int PRE, bool PADZ, int TAIL, bool R16>
+template <int NT, int KC, int PRE, bool PADZ, int TAIL, int DT, bool M16>
 int launch_r(const ConvK& k, hipStream_t stream) {
+    using P = MP<DT, M16>;
     const int npad = (int)vqae::round_up(k.Cout, 32);
     dim3 grid((unsigned)vqae::ceil_div(k.M, 128), (unsigned)vqae::ceil_div(npad, NT));
-    constexpr int lds_bytes = 2 * (128 + NT) * (KC + 4) * (int)sizeof(float);
+    constexpr int lds_bytes = 2 * (128 + NT) * (KC + P::PAD) * (int)sizeof(typename P::elem);
     static bool attr_set = false;
     if (!attr_set) {
-        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)conv_mfma_kernel<NT, KC, PRE, PADZ, TAIL, R16>,
+        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)conv_mfma_kernel<NT, KC, PRE, PADZ, TAIL, DT, M16>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         attr_set = true;
     }
     const int cls = (NT == 128 && KC == 32 && k.Cin >= 128) ? (k.ks == 3 ? vqae::PROF_CONV3X3_TRUNK : (k.ks == 1 ? vqae::PROF_CONV1X1_TRUNK : 0)) : 0;
     const double flops = 2.0 * k.M * (double)k.Cout * ((double)k.Ktot + (TAIL >= 1 ? (double)k.Cout : 0.0) + (TAIL == 2 ? (double)k.Cout : 0.0));
     vqae::ProfScope prof(cls, stream, flops);
-    conv_mfma_kernel<NT, KC, PRE, PADZ, TAIL, R16><<<grid, 256, lds_bytes, stream>>>(k);
+    conv_mfma_kernel<NT, KC, PRE, PADZ, TAIL, DT, M16><<<grid, 256, lds_bytes, stream>>>(k);
     prof.done();
     VQAE_LAUNCH_CHECK();
     return VQAE_OK;
@@ -502,8 +581,21 @@ int launch_r(const ConvK& k, hipStream_t stream) {
 
 template <int NT, int KC, int PRE, bool PADZ, int TAIL = 0>
 int launch(const ConvK& k, hipStream_t stream) {
-    if (k.dt != VQAE_DT_F32) return launch_r<NT, KC, PRE, PADZ, TAIL, true>(k, stream);
-    return launch_r<NT, KC, PRE, PADZ, TAIL, false>(k, stream);
+    if (k.m16) {          // 16-bit MFMA engine: KC in {32, 64}, circular / no padding only
+        if constexpr (!PADZ && KC >= 32) {
+            if (k.dt == VQAE_DT_BF16) return launch_r<NT, KC, PRE, PADZ, TAIL, VQAE_DT_BF16, true>(k, stream);
+            return launch_r<NT, KC, PRE, PADZ, TAIL, VQAE_DT_F16, true>(k, stream);
+        } else {
+            return vqae::fail(VQAE_ERR_UNSUPPORTED, "conv2d: 16-bit engine selected for an unsupported variant");
+        }
+    }
+    if constexpr (KC <= 32) {
+        if (k.dt == VQAE_DT_BF16) return launch_r<NT, KC, PRE, PADZ, TAIL, VQAE_DT_BF16, false>(k, stream);
+        if (k.dt == VQAE_DT_F16) return launch_r<NT, KC, PRE, PADZ, TAIL, VQAE_DT_F16, false>(k, stream);
+        return launch_r<NT, KC, PRE, PADZ, TAIL, VQAE_DT_F32, false>(k, stream);
+    } else {
+        return vqae::fail(VQAE_ERR_UNSUPPORTED, "conv2d: KC 64 needs the 16-bit engine");
+    }
 }
 
 template <int NT, int KC>
@@ -526,6 +618,7 @@ int launch_pre(const ConvK& k, hipStream_t stream) {
 template <int NT>
 int launch_kc(const ConvK& k, int kc, hipStream_t stream) {
     switch (kc) {
+        case 64: return launch_pre<NT, 64>(k, stream);
         case 32: return launch_pre<NT, 32>(k, stream);
         case 16: return launch_pre<NT, 16>(k, stream);
         default: return launch_pre<NT, 8>(k, stream);
@@ -581,7 +674,10 @@ int fill_conv(const vqae_conv_args* a, const float* x, const float* w, const flo
     VQAE_REQUIRE(k.pad_mode == VQAE_PAD_ZEROS || k.pad_mode == VQAE_PAD_CIRCULAR, VQAE_ERR_INVALID,
                  "conv2d: pad_mode %d", a->pad_mode);
     k.M = (int)M; k.Ktot = a->ksize * a->ksize * a->cin;
-    const int kc = (a->cin % 32 == 0) ? 32 : (a->cin % 16 == 0) ? 16 : 8;
+    static const bool no_m16 = getenv("VQAE_NO_MFMA16") && atoi(getenv("VQAE_NO_MFMA16"));
+    const bool padz = a->pad > 0 && a->pad_mode == VQAE_PAD_ZEROS;
+    k.m16 = (a->dtype != VQAE_DT_F32 && a->cin % 32 == 0 && !padz && !no_m16) ? 1 : 0;
+    const int kc = k.m16 ? ((a->cin % 64 == 0) ? 64 : 32) : ((a->cin % 32 == 0) ? 32 : (a->cin % 16 == 0) ? 16 : 8);
     k.n_chunks = a->cin / kc;
     k.n_steps = a->ksize * a->ksize * k.n_chunks;
     k.pre_mode = a->pre_mode; k.pre_a = a->pre_a; k.pre_b = a->pre_b;
@@ -627,10 +723,10 @@ int conv_trunk_tail(const vqae_conv_args* a, const float* t1, const float* w2, c
     k.w3 = w3; k.w1n = w1n; k.y2 = t1_next;
     k.t_scale = t_scale; k.t_b4 = t_b4; k.n_b1a = n_b1a; k.n_b1b = n_b1b; k.n_b2a = n_b2a; k.n_b2b = n_b2b;
     if (a->cin == 64) {
-        if (w1n) return launch<64, 32, VQAE_PRE_NONE, false, 2>(k, stream);
-        return launch<64, 32, VQAE_PRE_NONE, false, 1>(k, stream);
+        if (kc == 64) return w1n ? launch<64, 64, VQAE_PRE_NONE, false, 2>(k, stream) : launch<64, 64, VQAE_PRE_NONE, false, 1>(k, stream);
+        return w1n ? launch<64, 32, VQAE_PRE_NONE, false, 2>(k, stream) : launch<64, 32, VQAE_PRE_NONE, false, 1>(k, stream);
     }
-    if (w1n) return launch<128, 32, VQAE_PRE_NONE, false, 2>(k, stream);
-    return launch<128, 32, VQAE_PRE_NONE, false, 1>(k, stream);
+    if (kc == 64) return w1n ? launch<128, 64, VQAE_PRE_NONE, false, 2>(k, stream) : launch<128, 64, VQAE_PRE_NONE, false, 1>(k, stream);
+    return w1n ? launch<128, 32, VQAE_PRE_NONE, false, 2>(k, stream) : launch<128, 32, VQAE_PRE_NONE, false, 1>(k, stream);
 }
 }  // namespace vqae

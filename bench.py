@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--config", default="B", choices=["A", "B", "C"])
     ap.add_argument("--batch", type=int, default=256, help="patches per GPU per step")
     ap.add_argument("--mode", default="full", choices=["full", "encode"])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"],
+                    help="compute dtype of the convolutions (16-bit = torch.autocast semantics); headline: f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-class", type=int, default=1, help="kernel class timed for `roofline` (1 = trunk 3x3 conv)")
     args = ap.parse_args()
@@ -127,7 +129,7 @@ def main():
     spec = vqae_amd.SPECS[args.config]
     params = synth_weights(args.config)
     log("weights generated")
-    nat = vqae_amd.NativeVQAE(spec, params)
+    nat = vqae_amd.NativeVQAE(spec, params, compute_dtype=args.dtype)
     nat.reserve(args.batch, size, size)
     log("native handle created, workspace reserved")
 
@@ -195,7 +197,7 @@ def main():
                       else "patches/sec (Encoder.forward: encoder -> VQ indices)",
             "value": round(value, 2), "unit": "patches/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1] (cfg {args.config}): batch {B}/GPU of {size}x{size}x3 fp32 "
                                    f"patches -> {zh}x{zh} codes, K={spec.num_embeddings}, D={spec.code_dim}, "
                                    f"{args.mode} forward", "global_batch": world * B,
@@ -232,7 +234,7 @@ def main():
                                    "valu_frac_of_78.6Tops": round(alg / (avg_ms * 1e-3) / 78.6e12, 4)}
             res["roofline"]["frac"] = round(res["roofline"]["achieved"] / res["roofline"]["peak"], 4)
         # ---- CPU baseline beside it (rank 0, N = 1 only) -----------------------------------------
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.dtype == "f32":
             sb = 16 if size == 256 else 4                  # ~10-20 s of CPU work on the box's 16-core share
             log("cpu baseline ...")
             cb, cx, cout, cidx = cpu_baseline(args.config, size, params, embed, sb, 4)

@@ -1,3 +1,7 @@
+"""Debug helper (GPU box): run a small 16/32/64-channel model whose 64-channel blocks form a fused
+conv2+conv3+next-conv1 chain and compare the pre-VQ activations with the CPU oracle element by element.
+    VQAE_NO_TRUNK_FUSION=1 python tools/check_trunk_chain.py   # same with the 3-launch path
+"""
 import sys, os
 sys.path.insert(0, '/root/repo')
 import torch, vqae_amd

@@ -49,90 +49,111 @@ void vq_tier1_kernel(const float* __restrict__ z, const float* __restrict__ eT, 
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [<=VQ_TD][VQ_TK]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t row0 = ((int64_t)blockIdx.x * VQ_WAVES + wave) * VQ_RM;
 
-    const float* __restrict__ xrow[VQ_RM];
-#pragma unroll
-    for (int r = 0; r < VQ_RM; ++r) {
-        int64_t row = row0 + r;
-        if (row > N - 1) row = N - 1;             // clamp (stores are masked below)
-        xrow[r] = z + row * D;
+    auto load_tile = [&](int kt, int dt, int td) {
+        for (int i = threadIdx.x; i < td * (VQ_TK / 4); i += VQ_WAVES * 64) {
+            const int c = i >> 6, j4 = i & 63;
+            const float4 v = *reinterpret_cast<const float4*>(eT + (int64_t)(dt + c) * Kpad + kt + 4 * j4);
+            *reinterpret_cast<float4*>(lds + c * VQ_TK + 4 * j4) = v;
+        }
+    };
+    // Persistent workgroups: when the whole codebook is one LDS tile (K <= 256, D <= 128: cfg A / B) it is
+    // loaded once per workgroup and the row groups stream past it with no barrier in the loop.
+    const bool single_tile = (Kpad == VQ_TK) && (D <= VQ_TD);
+    if (single_tile) {
+        load_tile(0, 0, D);
+        __syncthreads();
     }
-    float b1[VQ_RM], b2[VQ_RM];
-    int i1[VQ_RM];
+    const int64_t n_groups = (N + VQ_ROWS_PER_BLOCK - 1) / VQ_ROWS_PER_BLOCK;
+    for (int64_t rg = blockIdx.x; rg < n_groups; rg += gridDim.x) {
+        const int64_t row0 = (rg * VQ_WAVES + wave) * VQ_RM;
+        const float* __restrict__ xrow[VQ_RM];
 #pragma unroll
-    for (int r = 0; r < VQ_RM; ++r) { b1[r] = INFINITY; b2[r] = INFINITY; i1[r] = 0; }
+        for (int r = 0; r < VQ_RM; ++r) {
+            int64_t row = row0 + r;
+            if (row > N - 1) row = N - 1;             // clamp (stores are masked below)
+            xrow[r] = z + row * D;
+        }
+        float b1[VQ_RM], b2[VQ_RM];
+        int i1[VQ_RM];
+#pragma unroll
+        for (int r = 0; r < VQ_RM; ++r) { b1[r] = INFINITY; b2[r] = INFINITY; i1[r] = 0; }
 
-    for (int kt = 0; kt < Kpad; kt += VQ_TK) {
-        float acc[VQ_RM][4];
+        for (int kt = 0; kt < Kpad; kt += VQ_TK) {
+            float acc[VQ_RM][4];
 #pragma unroll
-        for (int r = 0; r < VQ_RM; ++r) { acc[r][0] = 0.f; acc[r][1] = 0.f; acc[r][2] = 0.f; acc[r][3] = 0.f; }
+            for (int r = 0; r < VQ_RM; ++r) { acc[r][0] = 0.f; acc[r][1] = 0.f; acc[r][2] = 0.f; acc[r][3] = 0.f; }
 
-        for (int dt = 0; dt < D; dt += VQ_TD) {
-            const int td = (D - dt < VQ_TD) ? (D - dt) : VQ_TD;
-            __syncthreads();                      // previous tile fully consumed
-            for (int i = threadIdx.x; i < td * (VQ_TK / 4); i += VQ_WAVES * 64) {
-                const int c = i >> 6, j4 = i & 63;
-                const float4 v = *reinterpret_cast<const float4*>(eT + (int64_t)(dt + c) * Kpad + kt + 4 * j4);
-                *reinterpret_cast<float4*>(lds + c * VQ_TK + 4 * j4) = v;
-            }
-            __syncthreads();
-
-            for (int c4 = 0; c4 < td; c4 += 4) {
-                float4 xv[VQ_RM];
+            for (int dt = 0; dt < D; dt += VQ_TD) {
+                const int td = (D - dt < VQ_TD) ? (D - dt) : VQ_TD;
+                if (!single_tile) {
+                    __syncthreads();                  // previous tile fully consumed
+                    load_tile(kt, dt, td);
+                    __syncthreads();
+                }
+                // x values of the NEXT 4 channels are fetched (scalar loads) under the math of the current 4
+                float4 xn[VQ_RM];
 #pragma unroll
-                for (int r = 0; r < VQ_RM; ++r)   // wave-uniform address -> scalar load
-                    xv[r] = *reinterpret_cast<const float4*>(xrow[r] + dt + c4);
+                for (int r = 0; r < VQ_RM; ++r) xn[r] = *reinterpret_cast<const float4*>(xrow[r] + dt);
+                for (int c4 = 0; c4 < td; c4 += 4) {
+                    float4 xv[VQ_RM];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float4 e = *reinterpret_cast<const float4*>(lds + (c4 + j) * VQ_TK + 4 * lane);
+                    for (int r = 0; r < VQ_RM; ++r) xv[r] = xn[r];
+                    const int cn = (c4 + 4 < td) ? c4 + 4 : c4;     // last step re-reads its own channels
 #pragma unroll
-                    for (int r = 0; r < VQ_RM; ++r) {
-                        const float x = (j == 0) ? xv[r].x : (j == 1) ? xv[r].y : (j == 2) ? xv[r].z : xv[r].w;
-                        float d;
-                        d = x - e.x; d = d * d; acc[r][0] = __builtin_fmaf(d, d, acc[r][0]);
-                        d = x - e.y; d = d * d; acc[r][1] = __builtin_fmaf(d, d, acc[r][1]);
-                        d = x - e.z; d = d * d; acc[r][2] = __builtin_fmaf(d, d, acc[r][2]);
-                        d = x - e.w; d = d * d; acc[r][3] = __builtin_fmaf(d, d, acc[r][3]);
+                    for (int r = 0; r < VQ_RM; ++r)   // wave-uniform address -> scalar load
+                        xn[r] = *reinterpret_cast<const float4*>(xrow[r] + dt + cn);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float4 e = *reinterpret_cast<const float4*>(lds + (c4 + j) * VQ_TK + 4 * lane);
+#pragma unroll
+                        for (int r = 0; r < VQ_RM; ++r) {
+                            const float x = (j == 0) ? xv[r].x : (j == 1) ? xv[r].y : (j == 2) ? xv[r].z : xv[r].w;
+                            float d;
+                            d = x - e.x; d = d * d; acc[r][0] = __builtin_fmaf(d, d, acc[r][0]);
+                            d = x - e.y; d = d * d; acc[r][1] = __builtin_fmaf(d, d, acc[r][1]);
+                            d = x - e.z; d = d * d; acc[r][2] = __builtin_fmaf(d, d, acc[r][2]);
+                            d = x - e.w; d = d * d; acc[r][3] = __builtin_fmaf(d, d, acc[r][3]);
+                        }
                     }
                 }
             }
-        }
-        // fold this tile's 4 codes into the running (best, second, argmin); k ascends -> strict '<'
+            // fold this tile's 4 codes into the running (best, second, argmin); k ascends -> strict '<'
 #pragma unroll
-        for (int r = 0; r < VQ_RM; ++r) {
+            for (int r = 0; r < VQ_RM; ++r) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = kt + 4 * lane + j;
-                const float s = (k < K) ? acc[r][j] : INFINITY;
-                if (s < b1[r]) { b2[r] = b1[r]; b1[r] = s; i1[r] = k; }
-                else if (s < b2[r]) { b2[r] = s; }
+                for (int j = 0; j < 4; ++j) {
+                    const int k = kt + 4 * lane + j;
+                    const float s = (k < K) ? acc[r][j] : INFINITY;
+                    if (s < b1[r]) { b2[r] = b1[r]; b1[r] = s; i1[r] = k; }
+                    else if (s < b2[r]) { b2[r] = s; }
+                }
             }
         }
-    }
 
 #pragma unroll
-    for (int r = 0; r < VQ_RM; ++r) {
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const float ob1 = __shfl_xor(b1[r], off, 64);
-            const int oi1 = __shfl_xor(i1[r], off, 64);
-            const float ob2 = __shfl_xor(b2[r], off, 64);
-            merge_best(b1[r], i1[r], b2[r], ob1, oi1, ob2);
-        }
-    }
-    if (lane == 0) {
-#pragma unroll
         for (int r = 0; r < VQ_RM; ++r) {
-            const int64_t row = row0 + r;
-            if (row < N) {
-                idx32[row] = i1[r];
-                const float gap = b2[r] - b1[r];
-                const float rel = (b2[r] > 0.f) ? gap / b2[r] : 0.f;
-                if (margin) margin[row] = rel;
-                if (!(gap > thr * b2[r])) {        // inside evaluation noise, exact tie, or NaN
-                    const int slot = atomicAdd(flag_count, 1);
-                    flag_list[slot] = (int)row;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float ob1 = __shfl_xor(b1[r], off, 64);
+                const int oi1 = __shfl_xor(i1[r], off, 64);
+                const float ob2 = __shfl_xor(b2[r], off, 64);
+                merge_best(b1[r], i1[r], b2[r], ob1, oi1, ob2);
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < VQ_RM; ++r) {
+                const int64_t row = row0 + r;
+                if (row < N) {
+                    idx32[row] = i1[r];
+                    const float gap = b2[r] - b1[r];
+                    const float rel = (b2[r] > 0.f) ? gap / b2[r] : 0.f;
+                    if (margin) margin[row] = rel;
+                    if (!(gap > thr * b2[r])) {        // inside evaluation noise, exact tie, or NaN
+                        const int slot = atomicAdd(flag_count, 1);
+                        flag_list[slot] = (int)row;
+                    }
                 }
             }
         }
@@ -380,7 +401,8 @@ extern "C" int vqae_vq_forward_f32(const float* z, const float* embed, int64_t N
         }
         // evaluation-noise bound between tier-1 sums and the reference recipe's sums
         const float thr = (4.0f * (float)D + 16.0f) * 5.9604645e-8f;
-        const unsigned grid = (unsigned)vqae::ceil_div(N, VQ_ROWS_PER_BLOCK);
+        // one workgroup per CU (128 KB LDS tile); persistent over row groups
+        const unsigned grid = (unsigned)std::min<int64_t>(vqae::ceil_div(N, VQ_ROWS_PER_BLOCK), 256);
         vqae::ProfScope prof(vqae::PROF_VQ_TIER1, stream, 3.0 * (double)N * K * D);
         vq_tier1_kernel<<<grid, VQ_WAVES * 64, lds_bytes, stream>>>(z, w.eT, N, K, Kpad, D, thr, w.idx32, margin,
                                                                   w.flag_count, w.flag_list);

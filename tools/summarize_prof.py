@@ -21,7 +21,7 @@ def cls(name, grid, dur_us):
     """Split the trunk conv launches (same kernel symbol) into 3x3 / 1x1 by duration."""
     s = short(name)
     if "conv_mfma_kernel<128, 32" in s and grid == "524288":
-        return s + (" [trunk 3x3]" if dur_us > 400 else " [trunk 1x1]")
+        return s + (" [trunk block]" if dur_us > 400 else " [trunk 1x1]")
     return s
 
 

@@ -16,6 +16,7 @@ import torch
 from torch.utils.data import DataLoader, Dataset
 
 from . import dist as vdist
+from . import hdf5
 from . import ops
 
 MEAN = (0.7279, 0.5955, 0.7762)      # conf/transforms/camelyon16_transforms.yaml:15-23
@@ -185,17 +186,26 @@ def save_encodings(root, model, dataset, **kw):
     return written
 
 
-def convert_npy_to_hdf5(encodings_root, out_path):
-    """scripts/convert_npy_embeddings_to_hdf5/convert.py:27-32: one HDF5 group per sub-directory
-    (`images`, `masks`), one dataset per `.npy` stem.  Needs h5py (absent from the build image)."""
+def save_encodings_hdf5(out_path, model, dataset, **kw):
+    """BASELINE config 5 ("embeddings streamed to HDF5"): the slide grids of `get_encodings` go straight
+    into one HDF5 file -- group `images` / `masks`, dataset `<stem>` / `<stem>_mask` (the layout
+    convert.py:27-32 produces and datamodules/camelyon16.py:226-235 reads) -- without the `.npy` detour.
+    Every finished slide is appended at once; under torch.distributed only rank 0 writes."""
+    rank, _ = vdist.world()
+    writer = hdf5.H5Writer(out_path) if rank == 0 else None
     try:
-        import h5py
-    except ImportError as e:                          # stays loud: no silent alternative format
-        raise ImportError("convert_npy_to_hdf5 needs h5py, which is not installed in this image") from e
-    root = Path(encodings_root)
-    with h5py.File(str(out_path), "w") as f:
-        for sub in sorted(p for p in root.iterdir() if p.is_dir()):
-            g = f.create_group(sub.name)
-            for npy in sorted(sub.glob("*.npy")):
-                g.create_dataset(npy.stem, data=np.load(str(npy)))
+        for name, array in get_encodings(model, dataset, **kw):
+            if writer is not None:
+                group, _, stem = name.rpartition("/")
+                writer.create_dataset(group or "images", stem, array)
+    finally:
+        if writer is not None:
+            writer.close()
     return str(out_path)
+
+
+def convert_npy_to_hdf5(encodings_root, out_path=None):
+    """scripts/convert_npy_embeddings_to_hdf5/convert.py:27-32: one HDF5 group per sub-directory
+    (`images`, `masks`), one dataset per `.npy` stem.  Written by this package's own writer (hdf5.py;
+    h5py is not installed here); h5py / libhdf5 read the result."""
+    return hdf5.convert_npy_to_hdf5(encodings_root, out_path)

@@ -58,3 +58,29 @@ def test_module_mirror_works_with_driver(amd, oracle):
     ds_raw = SyntheticSlideDataset([(2, 2)], patch_size=32, raw=True)
     grids_raw = dict(get_encodings(nat, ds_raw, batch_size=3))
     assert np.array_equal(grids["images/slide_000"], grids_raw["images/slide_000"])
+
+
+def test_save_encodings_hdf5_streams_slide_grids(amd, oracle, tmp_path):
+    """BASELINE config 5 shape: slides -> HIP encoder -> stitched grids -> one HDF5 file (groups images/masks,
+    keys <stem> / <stem>_mask: convert.py:27-32, camelyon16.py:226-235)."""
+    from vqae_amd import hdf5
+    from vqae_amd.extract_embeddings import SyntheticSlideDataset, get_encodings, save_encodings, save_encodings_hdf5, convert_npy_to_hdf5
+    g = load_golden("model_tiny")
+    p = oracle.make_params(oracle.SPECS["tiny"], 0)
+    p["encoder.vq_layers.0.embed"] = torch.from_numpy(g["embed"])
+    nat = amd.NativeVQAE(amd.SPECS["tiny"], p)
+    ds = SyntheticSlideDataset([(3, 2), (1, 4), (2, 2)], patch_size=32, raw=True, names=["normal_001", "tumor_002", "test_003"])
+    want = dict(get_encodings(nat, ds, batch_size=7))
+    out = save_encodings_hdf5(tmp_path / "direct.hdf5", nat, ds, batch_size=7)
+    r = hdf5.H5Reader(out)
+    assert sorted(r.keys()) == ["images", "masks"]
+    for key in ("normal_001", "tumor_002", "test_003"):
+        a, m = r["images"][key], r["masks"][key + "_mask"]
+        assert a.dtype == want["images/" + key].dtype and np.array_equal(a, want["images/" + key])
+        assert m.dtype == want["masks/" + key + "_mask"].dtype and np.array_equal(m, want["masks/" + key + "_mask"])
+    # the reference's two-step route (.npy per slide, then the converter) gives the same file content
+    save_encodings(tmp_path, nat, ds, batch_size=7)
+    two_step = hdf5.read_hdf5(convert_npy_to_hdf5(tmp_path / "encodings"))
+    direct = hdf5.read_hdf5(out)
+    assert all(np.array_equal(two_step[g_][n], direct[g_][n]) and two_step[g_][n].dtype == direct[g_][n].dtype
+               for g_ in direct for n in direct[g_])

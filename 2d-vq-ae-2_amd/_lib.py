@@ -15,7 +15,10 @@ LIB_PATH = os.path.join(_HERE, "libvqae_hip.so")
 LAYOUT_NHWC, LAYOUT_NCHW = 0, 1
 IDX_I64, IDX_U8, IDX_U16, IDX_I32 = 0, 1, 2, 3
 PAD_NONE, PAD_CIRCULAR, PAD_ZEROS = 0, 1, 2
-PRE_NONE, PRE_BIAS, PRE_BIAS_ELU_BIAS = 0, 1, 2
+PRE_NONE, PRE_BIAS, PRE_BIAS_ELU_BIAS, PRE_CHANNEL_GATE = 0, 1, 2, 3
+ACT_NONE, ACT_ELU, ACT_SILU = 0, 1, 2
+DW_SAME, DW_DOWN, DW_UP = 0, 1, 2
+BLOCK_FIXUP, BLOCK_MBCONV = 0, 1
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 DTYPES = {"f32": DT_F32, "fp32": DT_F32, "float32": DT_F32, "bf16": DT_BF16, "bfloat16": DT_BF16,
           "f16": DT_F16, "fp16": DT_F16, "float16": DT_F16, "half": DT_F16}
@@ -49,7 +52,8 @@ class ConvArgs(Structure):
 class Config(Structure):
     _fields_ = [("in_channels", c_int), ("stem", c_int), ("n_down", c_int), ("n_pre", c_int), ("n_post", c_int),
                 ("n_enc", c_int), ("num_embeddings", c_int), ("projection_dim", c_int),
-                ("commitment_cost", c_float), ("compute_dtype", c_int)]
+                ("commitment_cost", c_float), ("compute_dtype", c_int),
+                ("block_kind", c_int), ("expand_ratio", c_int), ("se_divisor", c_int), ("bn_eps", c_float)]
 
 
 class Tensor(Structure):
@@ -70,6 +74,14 @@ SYMBOLS = {
     "vqae_conv_packed_floats": (c_size_t, [c_int, c_int, c_int]),
     "vqae_conv_pack_weight_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vqae_conv2d_f32": (c_int, [POINTER(ConvArgs), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vqae_conv2d_gated_f32": (c_int, [POINTER(ConvArgs), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p]),
+    "vqae_dw_partial_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "vqae_dwconv_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                c_void_p, c_void_p]),
+    "vqae_se_gate_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                 c_void_p, c_void_p]),
+    "vqae_pixel_shuffle2_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vqae_fixup_same_supported": (c_int, [c_int, c_int, c_int]),
     "vqae_fixup_same_block_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                           POINTER(c_float), c_int, c_void_p]),

@@ -42,6 +42,7 @@ struct ConvK {
     const float* __restrict__ w1n;       // packed [128][128] of the NEXT block's conv1 (TAIL == 2)
     float* y2;                           // [M][128]: next block's t1 (TAIL == 2)
     float t_scale, t_b4, n_b1a, n_b1b, n_b2a, n_b2b;
+    const float* __restrict__ gate;      // [B][Cin] per-image channel gate (PRE == VQAE_PRE_CHANNEL_GATE; MBConv SE)
     int dt;                              // VQAE_DT_*: autocast rounding points
     int m16;                             // 16-bit MFMA engine (dt != 0, cin % 32 == 0, no zero padding)
 };
@@ -192,6 +193,7 @@ void conv_mfma_kernel(const ConvK p) {
     int yo0[A_PT], yo1[A_PT], yo2[A_PT], xo0[A_PT], xo1[A_PT], xo2[A_PT];   // element offsets (relative to xb) per tap row / column
     unsigned zbits[A_PT];                            // bit (3*dy + dx): tap lies in the zero padding
     int a_wr[A_PT];                                  // LDS write offset (floats) of this thread's A pieces
+    int g_off[A_PT];                                 // PRE == CHANNEL_GATE: offset of this pixel's image row in p.gate
 #pragma unroll
     for (int i = 0; i < A_PT; ++i) {
         const int row = tid / C4 + i * (256 / C4);
@@ -201,6 +203,7 @@ void conv_mfma_kernel(const ConvK p) {
         const int b = m / hw_o, rem = m - b * hw_o;
         const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
         const int imgoff = (b - img0) * p.H * p.W * p.Cin;
+        g_off[i] = b * p.Cin + a_c4 * 4;
         unsigned zy = 0, zx = 0;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
@@ -248,13 +251,17 @@ void conv_mfma_kernel(const ConvK p) {
     };
     set_tap(0);
 
-    f32x4 ra[A_PT], rb[B_PT];
+    f32x4 ra[A_PT], rb[B_PT], rg[A_PT];
     unsigned raz = 0;
     auto gather = [&]() {                            // issue the loads of step (nx_tap, nx_chunk), then advance
         const float* xs = xb + nx_chunk * KC;                                          // uniform
         const float* ws = wbase + (nx_tap * p.n_chunks + nx_chunk) * KC;               // uniform
 #pragma unroll
         for (int i = 0; i < A_PT; ++i) ra[i] = *reinterpret_cast<const f32x4*>(xs + cur[i]);
+        if (PRE == VQAE_PRE_CHANNEL_GATE) {
+#pragma unroll
+            for (int i = 0; i < A_PT; ++i) rg[i] = *reinterpret_cast<const f32x4*>(p.gate + g_off[i] + nx_chunk * KC);
+        }
 #pragma unroll
         for (int i = 0; i < B_PT; ++i) rb[i] = *reinterpret_cast<const f32x4*>(ws + b_off[i]);
         raz = curz;
@@ -270,7 +277,9 @@ void conv_mfma_kernel(const ConvK p) {
 #pragma unroll
         for (int i = 0; i < A_PT; ++i) {
             f32x4 v = ra[i];
-            if (PRE != VQAE_PRE_NONE) {
+            if (PRE == VQAE_PRE_CHANNEL_GATE) {
+                v = v * rg[i];
+            } else if (PRE != VQAE_PRE_NONE) {
                 v = v + p.pre_a;
                 if (PRE == VQAE_PRE_BIAS_ELU_BIAS) {
 #pragma unroll
@@ -337,12 +346,12 @@ void conv_mfma_kernel(const ConvK p) {
     // the LDS stores of the gathered tile between the last ones, so the matrix pipe (64 cycles per
     // 32x32x2 MFMA) never drains while this wave issues memory instructions.
     constexpr int N_MFMA = M16 ? MI * NI * (KC / 16) : MI * NI * (KC / 2);   // MFMAs per wave per step
-    constexpr int N_LD = A_PT + B_PT;                // global loads / LDS stores per thread per step
+    constexpr int N_LD = A_PT + B_PT;                // LDS stores (and, without the gate, global loads) per thread per step
     auto step = [&](const elem* As, const elem* Bs, elem* Asn, elem* Bsn) {
         gather();
         compute(As, Bs);
         stage(Asn, Bsn);
-        if (!M16 && N_MFMA >= 4 * N_LD) {
+        if (!M16 && N_MFMA >= 4 * N_LD && PRE != VQAE_PRE_CHANNEL_GATE) {
 #pragma unroll
             for (int i = 0; i < N_LD; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
@@ -541,7 +550,8 @@ void conv_mfma_kernel(const ConvK p) {
                 if (p.has_scale) { t = t * p.scale; t = t + p.bias_s; }
                 else if (p.has_bias_s) { t = t + p.bias_s; }
                 if (p.residual) t = t + res[r];
-                if (p.has_act) t = elu1(t + p.act_a) + p.act_b;
+                if (p.has_act == VQAE_ACT_SILU) t = t / (1.0f + expf(-t));
+                else if (p.has_act) t = elu1(t + p.act_a) + p.act_b;
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), y_rsrc, base + ((r & 3) + 8 * (r >> 2)) * row_bytes, 0, 0);
             }
         }
@@ -601,6 +611,7 @@ int launch(const ConvK& k, hipStream_t stream) {
 template <int NT, int KC>
 int launch_pre(const ConvK& k, hipStream_t stream) {
     const bool padz = k.pad > 0 && k.pad_mode == VQAE_PAD_ZEROS;
+    if (padz && k.pre_mode == VQAE_PRE_CHANNEL_GATE) return vqae::fail(VQAE_ERR_UNSUPPORTED, "conv2d: gated load with zero padding");
     if (padz) {       // zero padding is only used by tests / generic callers: one (slower) variant
         switch (k.pre_mode) {
             case VQAE_PRE_NONE: return launch<NT, KC, VQAE_PRE_NONE, true>(k, stream);
@@ -611,6 +622,11 @@ int launch_pre(const ConvK& k, hipStream_t stream) {
     switch (k.pre_mode) {
         case VQAE_PRE_NONE: return launch<NT, KC, VQAE_PRE_NONE, false>(k, stream);
         case VQAE_PRE_BIAS: return launch<NT, KC, VQAE_PRE_BIAS, false>(k, stream);
+        case VQAE_PRE_CHANNEL_GATE:
+            if constexpr (KC == 32) {
+                if (k.dt == VQAE_DT_F32 && k.ks == 1) return launch_r<NT, KC, VQAE_PRE_CHANNEL_GATE, false, 0, VQAE_DT_F32, false>(k, stream);
+            }
+            return vqae::fail(VQAE_ERR_UNSUPPORTED, "conv2d: the gated operand load needs a fp32 1x1 conv with cin %% 32 == 0");
         default: return launch<NT, KC, VQAE_PRE_BIAS_ELU_BIAS, false>(k, stream);
     }
 }
@@ -660,7 +676,8 @@ int fill_conv(const vqae_conv_args* a, const float* x, const float* w, const flo
         VQAE_REQUIRE(a->pad <= a->in_h && a->pad <= a->in_w, VQAE_ERR_INVALID, "conv2d: circular pad larger than input");
     const int64_t M = (int64_t)a->batch * Ho * Wo;
     VQAE_REQUIRE(M < (1ll << 31) - 256, VQAE_ERR_UNSUPPORTED, "conv2d: too many output pixels (%lld)", (long long)M);
-    VQAE_REQUIRE(a->pre_mode >= VQAE_PRE_NONE && a->pre_mode <= VQAE_PRE_BIAS_ELU_BIAS, VQAE_ERR_INVALID, "conv2d: pre_mode %d", a->pre_mode);
+    VQAE_REQUIRE(a->pre_mode >= VQAE_PRE_NONE && a->pre_mode <= VQAE_PRE_CHANNEL_GATE, VQAE_ERR_INVALID, "conv2d: pre_mode %d", a->pre_mode);
+    VQAE_REQUIRE(a->has_act >= 0 && a->has_act <= VQAE_ACT_SILU, VQAE_ERR_INVALID, "conv2d: has_act %d", a->has_act);
     // lane offsets are 32-bit and relative to the first image of a 128-pixel tile (which spans at most
     // 128 / (Ho*Wo) + 2 images)
     VQAE_REQUIRE(((int64_t)128 / (Ho * Wo) + 3) * a->in_h * a->in_w * a->cin < (1ll << 30), VQAE_ERR_UNSUPPORTED,
@@ -691,8 +708,8 @@ int fill_conv(const vqae_conv_args* a, const float* x, const float* w, const flo
 }
 }  // namespace
 
-extern "C" int vqae_conv2d_f32(const vqae_conv_args* a, const float* x, const float* w, const float* bias_vec,
-                               const float* residual, float* y, void* stream_) {
+static int conv2d_impl(const vqae_conv_args* a, const float* x, const float* gate, const float* w, const float* bias_vec,
+                       const float* residual, float* y, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     VQAE_REQUIRE(a, VQAE_ERR_INVALID, "conv2d: null args");
     if (a->batch == 0) return VQAE_OK;
@@ -700,9 +717,23 @@ extern "C" int vqae_conv2d_f32(const vqae_conv_args* a, const float* x, const fl
     int kc;
     const int rc = fill_conv(a, x, w, bias_vec, residual, y, &k, &kc);
     if (rc) return rc;
+    VQAE_REQUIRE((a->pre_mode == VQAE_PRE_CHANNEL_GATE) == (gate != nullptr), VQAE_ERR_INVALID,
+                 "conv2d: VQAE_PRE_CHANNEL_GATE and the gate pointer go together (vqae_conv2d_gated_f32)");
+    k.gate = gate;
     if (a->cout <= 32) return launch_kc<32>(k, kc, stream);
     if (a->cout <= 64) return launch_kc<64>(k, kc, stream);
     return launch_kc<128>(k, kc, stream);
+}
+
+extern "C" int vqae_conv2d_f32(const vqae_conv_args* a, const float* x, const float* w, const float* bias_vec,
+                               const float* residual, float* y, void* stream) {
+    return conv2d_impl(a, x, nullptr, w, bias_vec, residual, y, stream);
+}
+
+extern "C" int vqae_conv2d_gated_f32(const vqae_conv_args* a, const float* x, const float* gate, const float* w,
+                                     const float* bias_vec, const float* residual, float* y, void* stream) {
+    VQAE_REQUIRE(gate, VQAE_ERR_INVALID, "conv2d_gated: null gate");
+    return conv2d_impl(a, x, gate, w, bias_vec, residual, y, stream);
 }
 
 namespace vqae {

@@ -6,6 +6,8 @@
 // handle (X = residual stream, P/Q/R = block temporaries).
 #include "common.h"
 
+#include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <string>
 #include <unordered_map>
@@ -78,6 +80,10 @@ struct Block {
     int mode, cin, cout, br;
     float b1a, b1b, b2a, b2b, b3a, b3b, b4, scale, b1c, b1d;
     float *w1, *w2, *w3, *wskip;          // packed, device
+    // MBConv (conv_block.py:240-321), BatchNorms folded: br = expanded width, w2 = depthwise taps [k*k][br]
+    int kind = VQAE_BLOCK_FIXUP, hidden = 0;
+    float *bv1 = nullptr, *bv2 = nullptr, *bv3 = nullptr;                        // folded BN shifts
+    float *fc0w = nullptr, *fc0b = nullptr, *fc2w = nullptr, *fc2b = nullptr;    // SELayer linears
 };
 
 // CAMELYON16 normalisation (conf/transforms/camelyon16_transforms.yaml:15-23), x255
@@ -106,6 +112,9 @@ struct vqae_handle {
     bool up_conv_first = true;             // fp32 up blocks: 1x1 convs before the bicubic resize (they commute)
     void* idx_scratch = nullptr;           // indices nobody asked for (vqae_forward with idx == NULL)
     size_t idx_scratch_bytes = 0;
+    float* se_ws = nullptr;                // MBConv: SE partial sums, then the gate [B][E]
+    size_t se_ws_floats = 0;
+    size_t se_gate_off = 0;
 };
 
 namespace {
@@ -192,6 +201,77 @@ int load_block(vqae_handle* h, const TensorMap& tm, const std::string& pre, int 
     return VQAE_OK;
 }
 
+// MBConv (conv_block.py:240-321) in eval mode.  Each BatchNorm2d (batchnorm2d.yaml: eps, running statistics) follows a
+// bias-free conv, so it folds into that conv: w' = w * g, shift = beta - mean * g, g = gamma / sqrt(var + eps).
+int bn_fold(const TensorMap& tm, const std::string& pre, int c, float eps, std::vector<float>* g, std::vector<float>* shift) {
+    const float *gamma, *beta, *mean, *var;
+    int rc;
+    if ((rc = find(tm, pre + ".weight", c, &gamma)) || (rc = find(tm, pre + ".bias", c, &beta)) ||
+        (rc = find(tm, pre + ".running_mean", c, &mean)) || (rc = find(tm, pre + ".running_var", c, &var))) return rc;
+    g->resize(c); shift->resize(c);
+    for (int i = 0; i < c; ++i) {
+        (*g)[i] = gamma[i] / std::sqrt(var[i] + eps);
+        (*shift)[i] = beta[i] - mean[i] * (*g)[i];
+    }
+    return VQAE_OK;
+}
+
+int load_mbconv(vqae_handle* h, const TensorMap& tm, const std::string& pre, int mode, int cin, int cout, Block* b) {
+    *b = Block();
+    b->kind = VQAE_BLOCK_MBCONV;
+    b->mode = mode; b->cin = cin; b->cout = cout;
+    const int e = (cin > cout ? cin : cout) * h->cfg.expand_ratio;               // conv_block.py:255-259
+    b->br = e;
+    const int div = h->cfg.se_divisor;
+    b->hidden = std::max(div, (int)(e + div / 2.0)) / div;                        // make_divisible, train_helpers.py:21-24
+    VQAE_REQUIRE(e % 32 == 0 && e <= 1024, VQAE_ERR_UNSUPPORTED, "MBConv: expanded width %d must be a multiple of 32, <= 1024", e);
+    const std::string br = pre + ".branch.";
+    const float eps = h->cfg.bn_eps;
+    std::vector<float> g, sh, w;
+    const float* p;
+    int rc;
+    // 0: 1x1 expand + 1: BN
+    if ((rc = find(tm, br + "0.weight", (int64_t)e * cin, &p)) || (rc = bn_fold(tm, br + "1", e, eps, &g, &sh))) return rc;
+    w.assign(p, p + (int64_t)e * cin);
+    for (int o = 0; o < e; ++o) for (int i = 0; i < cin; ++i) w[(int64_t)o * cin + i] *= g[o];
+    if ((rc = upload_packed(h, w.data(), e, cin, 1, &b->w1)) || (rc = upload(h, sh.data(), e, &b->bv1))) return rc;
+    // 3: depthwise + 4: BN   (Conv2d weight [e][1][k][k]; ConvTranspose2d weight [e][1][k][k], groups = e)
+    const int k2 = mode == MODE_SAME ? 3 : 2;
+    if ((rc = find(tm, br + "3.weight", (int64_t)e * k2 * k2, &p)) || (rc = bn_fold(tm, br + "4", e, eps, &g, &sh))) return rc;
+    w.assign((size_t)k2 * k2 * e, 0.f);
+    for (int c = 0; c < e; ++c) for (int t = 0; t < k2 * k2; ++t) w[(size_t)t * e + c] = p[(size_t)c * k2 * k2 + t] * g[c];
+    if ((rc = upload(h, w.data(), (int64_t)k2 * k2 * e, &b->w2)) || (rc = upload(h, sh.data(), e, &b->bv2))) return rc;
+    // 6: SELayer
+    if ((rc = find(tm, br + "6.fc.0.weight", (int64_t)b->hidden * e, &p)) || (rc = upload(h, p, (int64_t)b->hidden * e, &b->fc0w))) return rc;
+    if ((rc = find(tm, br + "6.fc.0.bias", b->hidden, &p)) || (rc = upload(h, p, b->hidden, &b->fc0b))) return rc;
+    if ((rc = find(tm, br + "6.fc.2.weight", (int64_t)e * b->hidden, &p)) || (rc = upload(h, p, (int64_t)e * b->hidden, &b->fc2w))) return rc;
+    if ((rc = find(tm, br + "6.fc.2.bias", e, &p)) || (rc = upload(h, p, e, &b->fc2b))) return rc;
+    // 7: 1x1 project + 8: BN
+    if ((rc = find(tm, br + "7.weight", (int64_t)cout * e, &p)) || (rc = bn_fold(tm, br + "8", cout, eps, &g, &sh))) return rc;
+    w.assign(p, p + (int64_t)cout * e);
+    for (int o = 0; o < cout; ++o) for (int i = 0; i < e; ++i) w[(int64_t)o * e + i] *= g[o];
+    if ((rc = upload_packed(h, w.data(), cout, e, 1, &b->w3)) || (rc = upload(h, sh.data(), cout, &b->bv3))) return rc;
+    // skip_conv (conv_block.py:303-310): none for 'same' with cin == cout
+    if (mode == MODE_DOWN) {
+        if ((rc = find(tm, pre + ".skip_conv.weight", (int64_t)cout * cin * 4, &p)) || (rc = upload_packed(h, p, cout, cin, 2, &b->wskip))) return rc;
+    } else if (mode == MODE_UP) {
+        // ConvTranspose2d weight [cin][cout][2][2] -> a 1x1 conv with 4*cout outputs ordered (a, b, co)
+        if ((rc = find(tm, pre + ".skip_conv.weight", (int64_t)cin * cout * 4, &p))) return rc;
+        w.assign((size_t)4 * cout * cin, 0.f);
+        for (int ci = 0; ci < cin; ++ci) for (int co = 0; co < cout; ++co) for (int t = 0; t < 4; ++t)
+            w[((size_t)t * cout + co) * cin + ci] = p[((size_t)ci * cout + co) * 4 + t];
+        if ((rc = upload_packed(h, w.data(), 4 * cout, cin, 1, &b->wskip))) return rc;
+    } else if (cin != cout) {
+        if ((rc = find(tm, pre + ".skip_conv.weight", (int64_t)cout * cin, &p)) || (rc = upload_packed(h, p, cout, cin, 1, &b->wskip))) return rc;
+    }
+    return VQAE_OK;
+}
+
+int load_any(vqae_handle* h, const TensorMap& tm, const std::string& pre, int mode, int cin, int cout, Block* b) {
+    return h->cfg.block_kind == VQAE_BLOCK_MBCONV ? load_mbconv(h, tm, pre, mode, cin, cout, b)
+                                                  : load_block(h, tm, pre, mode, cin, cout, b);
+}
+
 // ---- one conv launch --------------------------------------------------------------------------
 // compute dtype of the handle currently executing (set at the top of every entry point; handles are not
 // shared across threads)
@@ -210,9 +290,50 @@ struct ConvCall {
     ConvCall& bias(float b) { a.has_bias_s = 1; a.bias_s = b; return *this; }
 };
 
+// MBConv.forward (conv_block.py:316-321), eval mode, on NHWC buffers; on return buf[0] holds the output.
+//   X --1x1 (+shift1, SiLU)--> P [E] --depthwise (+shift2, SiLU, strip sums)--> Q [E] --SE gate--> g [B][E]
+//   out = conv1x1(Q * g) + shift3 + skip
+int run_mbconv(vqae_handle* h, const Block& b, int B, int& H, int& W, hipStream_t st) {
+    float *X = h->buf[0], *P = h->buf[1], *Q = h->buf[2], *R = h->buf[3];
+    float* partial = h->se_ws;
+    float* gate = h->se_ws + h->se_gate_off;
+    const int E = b.br;
+    int rc;
+    const float* skip = X;
+    int Ho = H, Wo = W;
+    if (b.mode == MODE_DOWN) {
+        ConvCall sk(B, H, W, b.cin, b.cout, 2, 2, 0, VQAE_PAD_NONE);
+        if ((rc = vqae_conv2d_f32(&sk.a, X, b.wskip, nullptr, nullptr, R, st))) return rc;
+        skip = R; Ho = H / 2; Wo = W / 2;
+    } else if (b.mode == MODE_UP) {
+        ConvCall sk(B, H, W, b.cin, 4 * b.cout, 1, 1, 0, VQAE_PAD_NONE);       // ConvTranspose2d(k2, s2) = 1x1 conv + pixel shuffle
+        if ((rc = vqae_conv2d_f32(&sk.a, X, b.wskip, nullptr, nullptr, Q, st))) return rc;
+        if ((rc = vqae_pixel_shuffle2_f32(Q, B, H, W, b.cout, R, st))) return rc;
+        skip = R; Ho = 2 * H; Wo = 2 * W;
+    } else if (b.wskip) {
+        ConvCall sk(B, H, W, b.cin, b.cout, 1, 1, 0, VQAE_PAD_NONE);
+        if ((rc = vqae_conv2d_f32(&sk.a, X, b.wskip, nullptr, nullptr, R, st))) return rc;
+        skip = R;
+    }
+    ConvCall c1(B, H, W, b.cin, E, 1, 1, 0, VQAE_PAD_NONE);
+    c1.a.has_act = VQAE_ACT_SILU;
+    if ((rc = vqae_conv2d_f32(&c1.a, X, b.w1, b.bv1, nullptr, P, st))) return rc;
+    const int dwm = b.mode == MODE_SAME ? VQAE_DW_SAME : (b.mode == MODE_DOWN ? VQAE_DW_DOWN : VQAE_DW_UP);
+    if ((rc = vqae_dwconv_f32(P, b.w2, b.bv2, B, H, W, E, dwm, 1, Q, partial, st))) return rc;
+    if ((rc = vqae_se_gate_f32(partial, B, Ho, Wo, E, b.fc0w, b.fc0b, b.hidden, b.fc2w, b.fc2b, gate, st))) return rc;
+    ConvCall c3(B, Ho, Wo, E, b.cout, 1, 1, 0, VQAE_PAD_NONE);
+    c3.a.pre_mode = VQAE_PRE_CHANNEL_GATE;
+    float* out = skip == X ? X : R;                                            // in-place residual add
+    if ((rc = vqae_conv2d_gated_f32(&c3.a, Q, gate, b.w3, b.bv3, skip, out, st))) return rc;
+    if (out == R) std::swap(h->buf[0], h->buf[3]);
+    H = Ho; W = Wo;
+    return VQAE_OK;
+}
+
 // PreActFixupResBlock.forward (conv_block.py:196-216) on NHWC buffers.  X holds the input and, on
 // return, buf[0] holds the output (buffers are swapped for down/up).
 int run_block(vqae_handle* h, const Block& b, const Block* next, int B, int& H, int& W, hipStream_t st) {
+    if (b.kind == VQAE_BLOCK_MBCONV) return run_mbconv(h, b, B, H, W, st);
     float *X = h->buf[0], *P = h->buf[1], *Q = h->buf[2], *R = h->buf[3];
     int rc;
     if (b.mode == MODE_SAME && (b.cin == 128 || b.cin == 64) && b.cout == b.cin && h->fuse_trunk) {
@@ -314,8 +435,9 @@ int run_block(vqae_handle* h, const Block& b, const Block* next, int B, int& H, 
 size_t max_floats_per_patch(const vqae_handle* h, int in_h, int in_w) {
     // largest NHWC intermediate: the bicubic-upsampled 2C tensor of the last up block / conv1 of the
     // first down block (both 2*stem channels at full resolution), or the code tensor.
-    size_t full = (size_t)in_h * in_w * (size_t)(2 * h->cfg.stem);
-    size_t lat = (size_t)(in_h >> h->cfg.n_down) * (in_w >> h->cfg.n_down) * (size_t)h->C;
+    const size_t widen = h->cfg.block_kind == VQAE_BLOCK_MBCONV ? (size_t)h->cfg.expand_ratio : 1;   // MBConv: expanded tensors
+    size_t full = (size_t)in_h * in_w * (size_t)(2 * h->cfg.stem) * widen;
+    size_t lat = (size_t)(in_h >> h->cfg.n_down) * (in_w >> h->cfg.n_down) * (size_t)h->C * widen;
     return full > lat ? full : lat;
 }
 
@@ -342,6 +464,28 @@ int ensure_workspace(vqae_handle* h, int B, int in_h, int in_w) {
         if (hipMalloc(&h->vq_ws, vq_need) != hipSuccess)
             return vqae::fail(VQAE_ERR_NOMEM, "vq workspace hipMalloc of %zu bytes failed", vq_need);
         h->vq_ws_bytes = vq_need;
+    }
+    if (h->cfg.block_kind == VQAE_BLOCK_MBCONV) {
+        // SE workspace: strip sums of the widest (image, level) + the gate; channels * pixels is largest at full resolution
+        const int e_max = 2 * h->cfg.stem * h->cfg.expand_ratio, e_lat = h->C * h->cfg.expand_ratio;
+        size_t part = vqae_dw_partial_floats(B, in_h, in_w, e_max);
+        const size_t part_lat = vqae_dw_partial_floats(B, in_h >> h->cfg.n_down, in_w >> h->cfg.n_down, e_lat);
+        if (part_lat > part) part = part_lat;
+        for (int l = 1; l < h->cfg.n_down; ++l) {                                 // intermediate levels
+            const size_t pl = vqae_dw_partial_floats(B, in_h >> l, in_w >> l, (2 * h->cfg.stem << l) * h->cfg.expand_ratio);
+            if (pl > part) part = pl;
+        }
+        const size_t gate_floats = (size_t)(B > 0 ? B : 1) * (size_t)(e_lat > e_max ? e_lat : e_max);
+        const size_t need_se = (size_t)vqae::round_up((int64_t)part, 64) + gate_floats;
+        if (need_se > h->se_ws_floats) {
+            VQAE_HIP_CHECK(hipDeviceSynchronize());
+            if (h->se_ws) (void)hipFree(h->se_ws);
+            h->se_ws = nullptr; h->se_ws_floats = 0;
+            if (hipMalloc((void**)&h->se_ws, need_se * 4) != hipSuccess)
+                return vqae::fail(VQAE_ERR_NOMEM, "SE workspace hipMalloc of %zu bytes failed", need_se * 4);
+            h->se_ws_floats = need_se;
+        }
+        h->se_gate_off = h->se_ws_floats - gate_floats;
     }
     const size_t idx_need = (size_t)vqae::round_up(rows * 4, 256);
     if (idx_need > h->idx_scratch_bytes) {
@@ -428,6 +572,13 @@ extern "C" int vqae_create(const vqae_config* cfg, const vqae_tensor* tensors, i
                  "projection_dim %d must be 0 or a multiple of 8", cfg->projection_dim);
     VQAE_REQUIRE(cfg->compute_dtype >= VQAE_DT_F32 && cfg->compute_dtype <= VQAE_DT_F16, VQAE_ERR_INVALID,
                  "compute_dtype %d", cfg->compute_dtype);
+    VQAE_REQUIRE(cfg->block_kind == VQAE_BLOCK_FIXUP || cfg->block_kind == VQAE_BLOCK_MBCONV, VQAE_ERR_INVALID,
+                 "block_kind %d", cfg->block_kind);
+    if (cfg->block_kind == VQAE_BLOCK_MBCONV) {
+        VQAE_REQUIRE(cfg->compute_dtype == VQAE_DT_F32, VQAE_ERR_UNSUPPORTED, "MBConv blocks run in fp32 only");
+        VQAE_REQUIRE(cfg->expand_ratio >= 1 && cfg->se_divisor >= 1 && cfg->bn_eps > 0.f, VQAE_ERR_INVALID,
+                     "MBConv: expand_ratio %d, se_divisor %d, bn_eps %g", cfg->expand_ratio, cfg->se_divisor, (double)cfg->bn_eps);
+    }
     TensorMap tm;
     for (int i = 0; i < n_tensors; ++i) tm[tensors[i].name] = &tensors[i];
 
@@ -460,20 +611,20 @@ extern "C" int vqae_create(const vqae_config* cfg, const vqae_tensor* tensors, i
             int bi = 0;
             Block b;
             for (int i = 0; i < cfg->n_pre; ++i, ++bi) {
-                if ((rc = load_block(h, tm, base + std::to_string(bi), MODE_SAME, c, c, &b))) return bail(rc);
+                if ((rc = load_any(h, tm, base + std::to_string(bi), MODE_SAME, c, c, &b))) return bail(rc);
                 h->enc.push_back(b);
             }
-            if ((rc = load_block(h, tm, base + std::to_string(bi), MODE_DOWN, c, 2 * c, &b))) return bail(rc);
+            if ((rc = load_any(h, tm, base + std::to_string(bi), MODE_DOWN, c, 2 * c, &b))) return bail(rc);
             h->enc.push_back(b); ++bi;
             for (int i = 0; i < cfg->n_post; ++i, ++bi) {
-                if ((rc = load_block(h, tm, base + std::to_string(bi), MODE_SAME, 2 * c, 2 * c, &b))) return bail(rc);
+                if ((rc = load_any(h, tm, base + std::to_string(bi), MODE_SAME, 2 * c, 2 * c, &b))) return bail(rc);
                 h->enc.push_back(b);
             }
             c *= 2;
         }
         for (int i = 0; i < cfg->n_enc; ++i) {
             Block b;
-            if ((rc = load_block(h, tm, "encoder.pre_enc_layers.0." + std::to_string(i), MODE_SAME, c, c, &b))) return bail(rc);
+            if ((rc = load_any(h, tm, "encoder.pre_enc_layers.0." + std::to_string(i), MODE_SAME, c, c, &b))) return bail(rc);
             h->enc.push_back(b);
         }
     }
@@ -496,7 +647,7 @@ extern "C" int vqae_create(const vqae_config* cfg, const vqae_tensor* tensors, i
         c = cfg->stem << cfg->n_down;
         for (int i = 0; i < cfg->n_enc; ++i) {
             Block b;
-            if ((rc = load_block(h, tm, "decoder.post_enc_layers.0." + std::to_string(i), MODE_SAME, c, c, &b))) return bail(rc);
+            if ((rc = load_any(h, tm, "decoder.post_enc_layers.0." + std::to_string(i), MODE_SAME, c, c, &b))) return bail(rc);
             h->dec.push_back(b);
         }
         for (int lvl = 0; lvl < cfg->n_down; ++lvl) {
@@ -504,13 +655,13 @@ extern "C" int vqae_create(const vqae_config* cfg, const vqae_tensor* tensors, i
             int bi = 0;
             Block b;
             for (int i = 0; i < cfg->n_pre; ++i, ++bi) {
-                if ((rc = load_block(h, tm, base + std::to_string(bi), MODE_SAME, c, c, &b))) return bail(rc);
+                if ((rc = load_any(h, tm, base + std::to_string(bi), MODE_SAME, c, c, &b))) return bail(rc);
                 h->dec.push_back(b);
             }
-            if ((rc = load_block(h, tm, base + std::to_string(bi), MODE_UP, c, c / 2, &b))) return bail(rc);
+            if ((rc = load_any(h, tm, base + std::to_string(bi), MODE_UP, c, c / 2, &b))) return bail(rc);
             h->dec.push_back(b); ++bi;
             for (int i = 0; i < cfg->n_post; ++i, ++bi) {
-                if ((rc = load_block(h, tm, base + std::to_string(bi), MODE_SAME, c / 2, c / 2, &b))) return bail(rc);
+                if ((rc = load_any(h, tm, base + std::to_string(bi), MODE_SAME, c / 2, c / 2, &b))) return bail(rc);
                 h->dec.push_back(b);
             }
             c /= 2;
@@ -531,6 +682,7 @@ extern "C" void vqae_destroy(vqae_handle* h) {
         if (h->buf[i]) (void)hipFree(h->buf[i]);
     if (h->vq_ws) (void)hipFree(h->vq_ws);
     if (h->idx_scratch) (void)hipFree(h->idx_scratch);
+    if (h->se_ws) (void)hipFree(h->se_ws);
     delete h;
 }
 
@@ -657,6 +809,21 @@ extern "C" double vqae_flops_per_patch(const vqae_handle* h, int in_h, int in_w,
     double fl = 0.0;
     auto blocks = [&](const std::vector<Block>& v, double H, double W) {
         for (const Block& b : v) {
+            if (b.kind == VQAE_BLOCK_MBCONV) {                                               // 1x1 expand, depthwise, 1x1 project, skip
+                const double k2 = b.mode == MODE_SAME ? 9.0 : 4.0;
+                fl += 2.0 * H * W * (double)b.cin * b.br;
+                if (b.mode == MODE_DOWN) {
+                    fl += 2.0 * (H / 2) * (W / 2) * (k2 * b.br + (double)b.br * b.cout + 4.0 * b.cin * b.cout);
+                    H /= 2; W /= 2;
+                } else if (b.mode == MODE_UP) {
+                    fl += 2.0 * H * W * 4.0 * b.cin * b.cout;
+                    H *= 2; W *= 2;
+                    fl += 2.0 * H * W * ((double)b.br + (double)b.br * b.cout);
+                } else {
+                    fl += 2.0 * H * W * (k2 * b.br + (double)b.br * b.cout + (b.wskip ? (double)b.cin * b.cout : 0.0));
+                }
+                continue;
+            }
             if (b.mode == MODE_SAME) {
                 fl += 2.0 * H * W * ((double)b.cin * b.br + 9.0 * b.br * b.br + (double)b.br * b.cout);
             } else if (b.mode == MODE_DOWN) {

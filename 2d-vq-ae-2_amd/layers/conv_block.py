@@ -138,10 +138,110 @@ class PreActFixupResBlock(nn.Module):
             return ops.nhwc_to_nchw(self.forward_nhwc(ops.nchw_to_nhwc(inp.detach().float())))
 
 
+class MBConv(nn.Module):
+    """Mirror of vq_ae.layers.conv_block.MBConv (conv_block.py:240-321), inference mode (BatchNorm running
+    statistics): `branch` = [0 1x1, 1 BN, 2 SiLU, 3 depthwise, 4 BN, 5 SiLU, 6 SELayer, 7 1x1, 8 BN] + `skip_conv`,
+    same state-dict names.  Only the shipped conf (mbconv.yaml: SiLU, BatchNorm2d, SELayer, bias-free convs) is
+    implemented; training-mode batch statistics are not."""
+
+    def __init__(self, in_channels: int, out_channels: int, mode: str, expand_ratio: float, activation_conf=None,
+                 conv_conf=None, batchnorm_conf=None, se_conf=None):
+        super().__init__()
+        from .misc import SELayer
+        assert mode in ("down", "same", "up", "out")                        # conv_block.py:254
+        max_channels = max(in_channels, out_channels)
+        assert isclose(max_channels * expand_ratio % 1, 0), (              # conv_block.py:256-258
+            f"max_channels: {max_channels} x expand_ratio: {expand_ratio} % 1 !≈ 0!")
+        e = round(max_channels * expand_ratio)
+        if activation_conf is not None and not str(activation_conf.get("_target_", "SiLU")).endswith("SiLU"):
+            raise NotImplementedError("MBConv: only SiLU is implemented (activation/silu.yaml)")
+        if batchnorm_conf is None or se_conf is None:
+            raise NotImplementedError("MBConv without BatchNorm / SELayer is not implemented (mbconv.yaml has both)")
+        bn_kw = {k: v for k, v in dict(batchnorm_conf).items() if k in ("eps", "momentum", "affine", "track_running_stats")}
+        if not bn_kw.get("affine", True) or not bn_kw.get("track_running_stats", True):
+            raise NotImplementedError("MBConv: BatchNorm2d must be affine with running statistics (batchnorm2d.yaml)")
+        cc = (conv_conf or {}).get(mode, {}) if conv_conf is not None else {}
+        for nm in ("branch_conv1", "branch_conv2", "branch_conv3", "skip_conv"):
+            if (cc.get(nm) or {}).get("bias", False):
+                raise NotImplementedError(f"MBConv: {nm} with bias is not implemented (mbconv.yaml: bias False)")
+        k2 = {"same": 3, "out": 3, "down": 2, "up": 2}[mode]
+        self.mode, self.in_channels, self.out_channels, self.expanded = mode, in_channels, out_channels, e
+        self.branch = nn.Sequential(
+            _Weight(e, in_channels, 1), nn.BatchNorm2d(e, **bn_kw), nn.SiLU(),
+            _Weight(e, 1, k2), nn.BatchNorm2d(e, **bn_kw), nn.SiLU(),
+            SELayer(e, e, int(se_conf.get("bottleneck_divisor", 4))),
+            _Weight(out_channels, e, 1), nn.BatchNorm2d(out_channels, **bn_kw))
+        if not (mode in ("same", "out") and in_channels == out_channels):  # conv_block.py:303-310
+            if mode == "up":                                                # ConvTranspose2d weight: [in][out][k][k]
+                self.skip_conv = _Weight(in_channels, out_channels, 2)
+            else:
+                self.skip_conv = _Weight(out_channels, in_channels, {"same": 1, "out": 3, "down": 2}[mode])
+        else:
+            self.skip_conv = None
+        with torch.no_grad():                                               # init batchnorm gamma to 0, :312-314
+            self.branch[-1].weight *= 0
+        self._prep = None
+
+    @staticmethod
+    def _fold(bn):
+        g = bn.weight.detach() / torch.sqrt(bn.running_var.detach() + bn.eps)
+        return g, bn.bias.detach() - bn.running_mean.detach() * g
+
+    def _prepared(self):
+        ts = [t for t in list(self.parameters()) + list(self.buffers())]
+        key = tuple((t._version, t.device) for t in ts)
+        if self._prep is None or self._prep[0] != key:
+            b = self.branch
+            g1, s1 = self._fold(b[1]); g2, s2 = self._fold(b[4]); g3, s3 = self._fold(b[8])
+            w1 = ops.pack_conv_weight((b[0].weight.detach() * g1.view(-1, 1, 1, 1)).contiguous())
+            e = self.expanded
+            taps = (b[3].weight.detach().reshape(e, -1) * g2.view(-1, 1)).t().contiguous()       # [k*k][e]
+            w3 = ops.pack_conv_weight((b[7].weight.detach() * g3.view(-1, 1, 1, 1)).contiguous())
+            sk = None
+            if self.skip_conv is not None:
+                w = self.skip_conv.weight.detach()
+                if self.mode == "up":      # [cin][cout][a][b] -> 1x1 conv with outputs ordered (a, b, cout)
+                    w = w.permute(2, 3, 1, 0).reshape(4 * self.out_channels, self.in_channels, 1, 1)
+                sk = ops.pack_conv_weight(w.contiguous())
+            self._prep = (key, dict(w1=w1, s1=s1.contiguous(), taps=taps, s2=s2.contiguous(), w3=w3,
+                                    s3=s3.contiguous(), sk=sk))
+        return self._prep[1]
+
+    def forward_nhwc(self, x):
+        """conv_block.py:316-321 on an NHWC tensor, eval mode."""
+        if self.training:
+            raise NotImplementedError("MBConv: training-mode BatchNorm is not implemented; call .eval()")
+        p = self._prepared()
+        B, H, W, _ = x.shape
+        e = self.expanded
+        t = ops.conv2d(x, p["w1"], e, 1, bias_vec=p["s1"], act="silu")
+        dwm = {"same": L.DW_SAME, "out": L.DW_SAME, "down": L.DW_DOWN, "up": L.DW_UP}[self.mode]
+        t, part = ops.dwconv(t, p["taps"], p["s2"], dwm, silu=True, want_partial=True)
+        gate = self.branch[6].gate_from_partial(part, B, t.shape[1], t.shape[2])
+        if self.skip_conv is None:
+            skip = x
+        elif self.mode == "same":
+            skip = ops.conv2d(x, p["sk"], self.out_channels, 1)
+        elif self.mode == "out":
+            skip = ops.conv2d(x, p["sk"], self.out_channels, 3, 1, 1, L.PAD_CIRCULAR)
+        elif self.mode == "down":
+            skip = ops.conv2d(x, p["sk"], self.out_channels, 2, 2, 0)
+        else:
+            skip = ops.pixel_shuffle2(ops.conv2d(x, p["sk"], 4 * self.out_channels, 1), self.out_channels)
+        return ops.conv2d(t, p["w3"], self.out_channels, 1, bias_vec=p["s3"], residual=skip, gate=gate)
+
+    def forward(self, inp: torch.Tensor):
+        with torch.no_grad():
+            return ops.nhwc_to_nchw(self.forward_nhwc(ops.nchw_to_nhwc(inp.detach().float())))
+
+
 def _build(conf, **kw):
     """Instantiate a block conf dict ({'_target_': ..., kwargs}) with our classes."""
+    target = str(dict(conf).get("_target_", ""))
     conf = {k: v for k, v in dict(conf).items() if k not in ("_target_", "_recursive_", "_convert_", "_partial_")}
     conf.update(kw)
+    if target.endswith("MBConv") or "expand_ratio" in conf:
+        return MBConv(**conf)
     return PreActFixupResBlock(**conf)
 
 

@@ -12,7 +12,7 @@ from typing import Sequence
 import torch
 from torch import nn
 
-from .layers.conv_block import DownBlock, PreActFixupResBlock, UpBlock
+from .layers.conv_block import DownBlock, MBConv, PreActFixupResBlock, UpBlock, _build
 from .layers.vq import EMAVectorQuantizer, ProjectedEMAVectorQuantizer2d
 from .native import NativeVQAE
 from .spec import VQAESpec
@@ -49,6 +49,19 @@ def _make_stem(conf, what):
             (3, 1, 1, "zeros", True):
         raise NotImplementedError(f"{what}: only Conv2d(k3,s1,p1,zeros,bias) is implemented (same2d.yaml)")
     return nn.Conv2d(c["in_channels"], c["out_channels"], 3, padding=1)
+
+
+def _block_hp(conv_block_conf):
+    """VQAESpec fields that select the conv block family (Fixup | MBConv) from its conf dict."""
+    c = dict(conv_block_conf)
+    if str(c.get("_target_", "")).endswith("MBConv") or "expand_ratio" in c:
+        er = c.get("expand_ratio", 4)
+        if int(er) != er:
+            raise NotImplementedError(f"MBConv expand_ratio {er}: only integer ratios are implemented")
+        return dict(block="mbconv", expand_ratio=int(er),
+                    se_divisor=int((c.get("se_conf") or {}).get("bottleneck_divisor", 4)),
+                    bn_eps=float((c.get("batchnorm_conf") or {}).get("eps", 1e-5)))
+    return {}
 
 
 class _NativeMixin:
@@ -107,9 +120,8 @@ class Encoder(_NativeMixin, nn.Module):
         down.pop("in_channels", None)
         self.down_layers = nn.ModuleList([DownBlock(in_channels=self.in_stem.out_channels, **down)])
         c = self.down_layers[0].out_channels
-        blk = _strip(conv_block_conf)
-        blk.update(mode="same", in_channels=c, out_channels=c)
-        self.pre_enc_layers = nn.ModuleList([nn.Sequential(*(PreActFixupResBlock(**blk) for _ in range(n_enc)))])
+        self.pre_enc_layers = nn.ModuleList([nn.Sequential(*(
+            _build(conv_block_conf, mode="same", in_channels=c, out_channels=c) for _ in range(n_enc)))])
         vq = _strip(vq_levels[0])
         projected = "projection_dim" in vq
         self.vq_layers = nn.ModuleList([(ProjectedEMAVectorQuantizer2d if projected else EMAVectorQuantizer)(**vq)])
@@ -119,7 +131,7 @@ class Encoder(_NativeMixin, nn.Module):
                         n_pre=down.get("n_pre_layers") or 0, n_post=down.get("n_post_layers") or 0, n_enc=n_enc,
                         num_embeddings=vq["num_embeddings"], projection_dim=vq.get("projection_dim", 0),
                         commitment_cost=float(vq["commitment_cost"]), decay=float(vq["decay"]),
-                        laplace_alpha=float(vq["laplace_alpha"]))
+                        laplace_alpha=float(vq["laplace_alpha"]), **_block_hp(conv_block_conf))
 
     def _spec(self):
         return VQAESpec(**self._hp)
@@ -144,12 +156,11 @@ class Decoder(_NativeMixin, nn.Module):
         up.pop("out_channels", None)
         self.up_layers = nn.ModuleList([UpBlock(out_channels=self.out_stem.in_channels, **up)])
         c = self.up_layers[0].in_channels
-        blk = _strip(conv_block_conf)
-        blk.update(mode="same", in_channels=c, out_channels=c)
-        self.post_enc_layers = nn.ModuleList([nn.Sequential(*(PreActFixupResBlock(**blk) for _ in range(n_enc)))])
+        self.post_enc_layers = nn.ModuleList([nn.Sequential(*(
+            _build(conv_block_conf, mode="same", in_channels=c, out_channels=c) for _ in range(n_enc)))])
         self._hp = dict(stem=self.out_stem.in_channels, in_channels=self.out_stem.out_channels, n_down=up["n_up"],
                         n_pre=up.get("n_pre_layers") or 0, n_post=up.get("n_post_layers") or 0, n_enc=n_enc,
-                        num_embeddings=1, projection_dim=0)
+                        num_embeddings=1, projection_dim=0, **_block_hp(conv_block_conf))
 
     def _spec(self):
         return VQAESpec(**self._hp)
@@ -201,6 +212,20 @@ def default_confs(spec: VQAESpec):
                 "dilation": 1, "groups": 1, "bias": bias, "padding_mode": padding_mode}
     proj = lambda: conv(1, bias=False)
     n_layers = (spec.n_down * spec.n_pre * spec.n_post) * 2 + 2 * spec.n_enc     # n_layers.yaml:3
+    circ3 = lambda: conv(3, 1, 1, False, "circular")
+    down2 = lambda: conv(2, 2, bias=False, padding_mode="circular")
+    up2 = lambda: {"in_channels": None, "out_channels": None, "kernel_size": 2, "stride": 2, "padding": 0,
+                   "output_padding": 0, "groups": 1, "bias": False, "dilation": 1, "padding_mode": "zeros"}
+    mb = {"_target_": "vqae_amd.layers.conv_block.MBConv", "_recursive_": False, "expand_ratio": spec.expand_ratio,
+          "activation_conf": {"_target_": "torch.nn.SiLU"},
+          "se_conf": {"_target_": "vqae_amd.layers.misc.SELayer", "bottleneck_divisor": spec.se_divisor},
+          "batchnorm_conf": {"_target_": "torch.nn.BatchNorm2d", "eps": spec.bn_eps, "momentum": 0.1, "affine": True,
+                             "track_running_stats": True},
+          "conv_conf": {
+              "down": {"branch_conv1": proj(), "branch_conv2": down2(), "branch_conv3": proj(), "skip_conv": down2()},
+              "up": {"branch_conv1": proj(), "branch_conv2": up2(), "branch_conv3": proj(), "skip_conv": up2()},
+              "same": {"branch_conv1": proj(), "branch_conv2": circ3(), "branch_conv3": proj(), "skip_conv": proj()},
+              "out": {"branch_conv1": proj(), "branch_conv2": circ3(), "branch_conv3": proj(), "skip_conv": circ3()}}}
     fx = {"_target_": "vqae_amd.layers.conv_block.PreActFixupResBlock", "_recursive_": False,
           "bottleneck_divisor": 1, "n_layers": n_layers,
           "activation": {"_target_": "torch.nn.ELU", "alpha": 1.0},
@@ -210,6 +235,8 @@ def default_confs(spec: VQAESpec):
               "up": {"branch_conv1": proj(), "branch_conv2": proj(), "branch_conv3": proj(), "skip_conv": proj()},
               "same": {"branch_conv1": proj(), "branch_conv2": conv(3, 1, 1, False, "circular"),
                        "branch_conv3": proj(), "skip_conv": proj()}}}
+    if spec.block == "mbconv":                   # conf/model/{encoder,decoder}/efficientnetv2.yaml
+        fx = mb
     vq = {"num_embeddings": spec.num_embeddings, "embedding_dim": spec.channels,
           "commitment_cost": spec.commitment_cost, "decay": spec.decay, "laplace_alpha": spec.laplace_alpha}
     if spec.projection_dim > 0:

@@ -8,7 +8,7 @@ from . import _lib as L
 from . import ops
 from .spec import VQAESpec
 
-_BUFFER_ONLY = ("embed_avg", "cluster_size", "first_pass")
+_BUFFER_ONLY = ("embed_avg", "cluster_size", "first_pass", "num_batches_tracked")
 
 
 class NativeVQAE:
@@ -21,7 +21,9 @@ class NativeVQAE:
         self.spec = spec
         self.compute_dtype = L.dtype_code(compute_dtype)
         cfg = L.Config(spec.in_channels, spec.stem, spec.n_down, spec.n_pre, spec.n_post, spec.n_enc,
-                       spec.num_embeddings, spec.projection_dim, float(spec.commitment_cost), self.compute_dtype)
+                       spec.num_embeddings, spec.projection_dim, float(spec.commitment_cost), self.compute_dtype,
+                       L.BLOCK_MBCONV if spec.block == "mbconv" else L.BLOCK_FIXUP, spec.expand_ratio,
+                       spec.se_divisor, float(spec.bn_eps))
         keep, items = [], []
         for name, t in state_dict.items():
             if name.endswith(_BUFFER_ONLY):

@@ -64,8 +64,9 @@ def pack_conv_weight(w, dtype=None):
 
 
 def conv2d(x, w_packed, cout, ksize, stride=1, pad=0, pad_mode=L.PAD_NONE, pre=None, act=None, scale_bias=None,
-           bias_s=None, bias_vec=None, residual=None, out=None, dtype=None):
-    """NHWC fp32 conv through vqae_conv2d_f32.  pre = (a,) or (a, b); act = (a, b); scale_bias = (s, b)."""
+           bias_s=None, bias_vec=None, residual=None, out=None, dtype=None, gate=None):
+    """NHWC fp32 conv through vqae_conv2d_f32.  pre = (a,) or (a, b); act = (a, b) [ELU form] or 'silu';
+    scale_bias = (s, b); gate [B, cin]: per-image channel gate applied while x is loaded (vqae_conv2d_gated_f32)."""
     _need_gpu(x, w_packed)
     x = x.contiguous()
     B, H, W, cin = x.shape
@@ -78,8 +79,11 @@ def conv2d(x, w_packed, cout, ksize, stride=1, pad=0, pad_mode=L.PAD_NONE, pre=N
             a.pre_mode, a.pre_a = L.PRE_BIAS, float(pre[0])
         else:
             a.pre_mode, a.pre_a, a.pre_b = L.PRE_BIAS_ELU_BIAS, float(pre[0]), float(pre[1])
-    if act is not None:
-        a.has_act, a.act_a, a.act_b = 1, float(act[0]), float(act[1])
+    if isinstance(act, str):
+        assert act == "silu", act
+        a.has_act = L.ACT_SILU
+    elif act is not None:
+        a.has_act, a.act_a, a.act_b = L.ACT_ELU, float(act[0]), float(act[1])
     if scale_bias is not None:
         a.has_scale, a.scale, a.bias_s = 1, float(scale_bias[0]), float(scale_bias[1])
     elif bias_s is not None:
@@ -88,9 +92,53 @@ def conv2d(x, w_packed, cout, ksize, stride=1, pad=0, pad_mode=L.PAD_NONE, pre=N
     Wo = (W + 2 * pad - ksize) // stride + 1
     if out is None:
         out = torch.empty((B, Ho, Wo, cout), dtype=torch.float32, device=x.device)
+    if gate is not None:
+        assert pre is None and tuple(gate.shape) == (B, cin), (pre, gate.shape)
+        _need_gpu(gate)
+        a.pre_mode = L.PRE_CHANNEL_GATE
+        L.check(L.lib().vqae_conv2d_gated_f32(ctypes.byref(a), _p(x), _p(gate.contiguous()), _p(w_packed), _p(bias_vec),
+                                              _p(residual), _p(out), _stream()))
+        return out
     L.check(L.lib().vqae_conv2d_f32(ctypes.byref(a), _p(x), _p(w_packed), _p(bias_vec), _p(residual), _p(out),
                                     _stream()))
     return out
+
+
+def dwconv(x, w_taps, bias=None, mode=L.DW_SAME, silu=False, want_partial=False):
+    """Depthwise conv on NHWC x [B,H,W,C]; w_taps [k*k, C].  mode: DW_SAME (3x3 circular), DW_DOWN (2x2 s2),
+    DW_UP (ConvTranspose2d 2x2 s2).  -> y, or (y, strip partial sums) for se_gate."""
+    _need_gpu(x, w_taps)
+    x = x.contiguous()
+    B, H, W, C = x.shape
+    Ho, Wo = {L.DW_SAME: (H, W), L.DW_DOWN: (H // 2, W // 2), L.DW_UP: (2 * H, 2 * W)}[mode]
+    y = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=x.device)
+    part = None
+    if want_partial:
+        part = torch.empty(int(L.lib().vqae_dw_partial_floats(B, Ho, Wo, C)), dtype=torch.float32, device=x.device)
+    L.check(L.lib().vqae_dwconv_f32(_p(x), _p(w_taps.contiguous()), _p(bias), B, H, W, C, mode, int(silu), _p(y), _p(part),
+                                    _stream()))
+    return (y, part) if want_partial else y
+
+
+def se_gate(partial, batch, out_h, out_w, fc0_w, fc0_b, fc2_w, fc2_b):
+    """SELayer gate [B, C] from dwconv's strip sums (layers/misc.py:23-29)."""
+    _need_gpu(partial, fc0_w, fc0_b, fc2_w, fc2_b)
+    hidden, C = fc0_w.shape
+    gate = torch.empty((batch, C), dtype=torch.float32, device=partial.device)
+    L.check(L.lib().vqae_se_gate_f32(_p(partial), batch, out_h, out_w, C, _p(fc0_w.contiguous()), _p(fc0_b.contiguous()),
+                                     hidden, _p(fc2_w.contiguous()), _p(fc2_b.contiguous()), _p(gate), _stream()))
+    return gate
+
+
+def pixel_shuffle2(x, c):
+    """[B,H,W,4c] (a, b, c) -> [B,2H,2W,c]."""
+    _need_gpu(x)
+    x = x.contiguous()
+    B, H, W, c4 = x.shape
+    assert c4 == 4 * c
+    y = torch.empty((B, 2 * H, 2 * W, c), dtype=torch.float32, device=x.device)
+    L.check(L.lib().vqae_pixel_shuffle2_f32(_p(x), B, H, W, c, _p(y), _stream()))
+    return y
 
 
 def fixup_same_supported(c, h, w):

@@ -17,6 +17,10 @@ class VQAESpec:
     commitment_cost: float = 1.0  # ema_vq.yaml:4
     decay: float = 0.99           # ema_vq.yaml:5
     laplace_alpha: float = 1e-5   # ema_vq.yaml:6
+    block: str = "fixup"          # "fixup" (pre_activation_fixup.yaml) | "mbconv" (conf/model/encoder/efficientnetv2.yaml:3-4)
+    expand_ratio: int = 4         # mbconv.yaml:32
+    se_divisor: int = 4           # layers/misc/se.yaml:5
+    bn_eps: float = 1e-5          # layers/misc/batchnorm2d.yaml:4
 
     @property
     def channels(self) -> int:    # embedding_dim = stem * 2**n_down (vq_ae.yaml:32)
@@ -37,6 +41,9 @@ SPECS = {
     "C": VQAESpec(stem=32, n_down=3, n_enc=50, num_embeddings=1024, projection_dim=0),   # BASELINE config 4
     "tiny": VQAESpec(stem=8, n_down=2, n_pre=1, n_post=1, n_enc=2, num_embeddings=16, projection_dim=0),
     "tinyP": VQAESpec(stem=8, n_down=2, n_pre=1, n_post=1, n_enc=2, num_embeddings=32, projection_dim=8),
+    # MBConv / EfficientNetV2 variant
+    "tinyM": VQAESpec(stem=8, n_down=2, n_pre=1, n_post=1, n_enc=2, num_embeddings=16, block="mbconv"),
+    "BM": VQAESpec(stem=16, n_down=3, n_enc=50, num_embeddings=256, block="mbconv"),
 }
 
 

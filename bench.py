@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="B", choices=["A", "B", "C"])
+    ap.add_argument("--config", default="B", choices=["A", "B", "C", "BM"])
     ap.add_argument("--batch", type=int, default=256, help="patches per GPU per step")
     ap.add_argument("--mode", default="full", choices=["full", "encode"])
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"],

@@ -95,7 +95,8 @@ int vqae_vq_ema_update_f32(float* embed_dev, float* embed_avg_dev, float* cluste
  * ------------------------------------------------------------------------------------------- */
 
 enum { VQAE_PAD_NONE = 0, VQAE_PAD_CIRCULAR = 1, VQAE_PAD_ZEROS = 2 };
-enum { VQAE_PRE_NONE = 0, VQAE_PRE_BIAS = 1, VQAE_PRE_BIAS_ELU_BIAS = 2 };
+enum { VQAE_PRE_NONE = 0, VQAE_PRE_BIAS = 1, VQAE_PRE_BIAS_ELU_BIAS = 2, VQAE_PRE_CHANNEL_GATE = 3 };
+enum { VQAE_ACT_NONE = 0, VQAE_ACT_ELU = 1, VQAE_ACT_SILU = 2 };      /* vqae_conv_args.has_act */
 
 /* Floats needed for the packed form of a [cout][cin][k][k] weight (rows padded to 32 couts). */
 size_t vqae_conv_packed_floats(int cout, int cin, int ksize);
@@ -113,14 +114,17 @@ typedef struct vqae_conv_args {
     int pad_mode;         /* VQAE_PAD_* (circular: padding_mode='circular', pre_activation_fixup.yaml:56-58) */
     /* pre-op on the input (Fixup scalar biases, conv_block.py:199-206,211):
      *   VQAE_PRE_BIAS:           x + pre_a
-     *   VQAE_PRE_BIAS_ELU_BIAS:  ELU(x + pre_a) + pre_b        (ELU alpha = 1, activation/elu.yaml) */
+     *   VQAE_PRE_BIAS_ELU_BIAS:  ELU(x + pre_a) + pre_b        (ELU alpha = 1, activation/elu.yaml)
+     *   VQAE_PRE_CHANNEL_GATE:   x * gate[b][ci]               (SELayer's `x * y`, layers/misc.py:30; only through
+     *                                                           vqae_conv2d_gated_f32: fp32, 1x1, cin % 32 == 0) */
     int pre_mode;
     float pre_a, pre_b;
     /* epilogue, in the reference's rounding order (conv_block.py:208-214):
      *   t = acc; if (bias_vec) t = t + bias_vec[c];  (the conv's own bias)   t = round_dtype(t);
      *   if (has_scale) t = t * scale + bias_s;  else if (has_bias_s) t = t + bias_s;
      *   if (residual) t = t + residual[m][c];
-     *   if (has_act) t = ELU(t + act_a) + act_b;   (the NEXT conv's pre-op, fused here) */
+     *   has_act == VQAE_ACT_ELU:  t = ELU(t + act_a) + act_b;   (the NEXT conv's pre-op, fused here)
+     *   has_act == VQAE_ACT_SILU: t = t * sigmoid(t)            (MBConv: activation/silu.yaml after the folded BN) */
     int has_scale, has_bias_s, has_act;
     float scale, bias_s, act_a, act_b;
     int dtype;            /* VQAE_DT_*: autocast rounding of operands (after the pre-op) and of acc (+ bias_vec) */
@@ -131,6 +135,34 @@ typedef struct vqae_conv_args {
  * Requires cin % 8 == 0 (use vqae_conv_small_cin_f32 for the 3-channel stem). */
 int vqae_conv2d_f32(const vqae_conv_args* a, const float* x_dev, const float* w_packed_dev,
                     const float* bias_vec_dev, const float* residual_dev, float* y_dev, void* stream);
+
+/* Same conv with the input multiplied by a per-(image, input channel) gate [B][cin] while it is loaded
+ * (a->pre_mode == VQAE_PRE_CHANNEL_GATE): conv3 of an MBConv consuming SELayer's output without materialising it
+ * (conv_block.py:290-297, layers/misc.py:30). */
+int vqae_conv2d_gated_f32(const vqae_conv_args* a, const float* x_dev, const float* gate_dev, const float* w_packed_dev,
+                          const float* bias_vec_dev, const float* residual_dev, float* y_dev, void* stream);
+
+/* ---- MBConv pieces (vq_ae/layers/conv_block.py:240-321; BatchNorms folded into weights/bias by the caller) ----
+ * Depthwise conv over NHWC x [B][H][W][C] (branch_conv2 with groups = C, conv_block.py:276-281):
+ *   VQAE_DW_SAME  3x3 / stride 1 / circular pad     (same2d.yaml + padding_mode circular, mbconv.yaml:60-63)
+ *   VQAE_DW_DOWN  2x2 / stride 2                     (down2d.yaml)
+ *   VQAE_DW_UP    ConvTranspose2d 2x2 / stride 2     (up2d.yaml)
+ * w_taps_dev [k*k][C] (tap-major), bias_dev [C] or NULL, optional SiLU; y_dev [B][Ho][Wo][C].
+ * If partial_dev != NULL (vqae_dw_partial_floats() floats) it receives per-(image, 256-pixel strip, channel) sums of
+ * y for SELayer's spatial mean, reduced in a fixed order (bit-reproducible run to run). */
+enum { VQAE_DW_SAME = 0, VQAE_DW_DOWN = 1, VQAE_DW_UP = 2 };
+size_t vqae_dw_partial_floats(int batch, int out_h, int out_w, int channels);
+int vqae_dwconv_f32(const float* x_dev, const float* w_taps_dev, const float* bias_dev, int batch, int h, int w,
+                    int channels, int mode, int silu, float* y_dev, float* partial_dev, void* stream);
+/* SELayer.forward up to the gate (layers/misc.py:23-29): mean over (out_h, out_w) from the partial sums ->
+ * Linear(channels, hidden) -> SiLU -> Linear(hidden, channels) -> sigmoid; gate_dev [B][channels].
+ * fc*_w are nn.Linear weights [out][in] on the device. */
+int vqae_se_gate_f32(const float* partial_dev, int batch, int out_h, int out_w, int channels, const float* fc0_w_dev,
+                     const float* fc0_b_dev, int hidden, const float* fc2_w_dev, const float* fc2_b_dev, float* gate_dev,
+                     void* stream);
+/* x [B][H][W][4*c] with channel order (a, b, c) -> y [B][2H][2W][c], y[2i+a][2j+b] = x[i][j][(a, b, :)]: the pixel
+ * placement of ConvTranspose2d(k = 2, s = 2) (skip_conv of an 'up' MBConv) after its channel mixing ran as a 1x1 conv. */
+int vqae_pixel_shuffle2_f32(const float* x_dev, int batch, int h, int w, int c, float* y_dev, void* stream);
 
 /* One whole PreActFixupResBlock.forward, mode 'same' (conv_block.py:196-216: 1x1 -> 3x3 circular -> 1x1,
  * in_channels == out_channels == c) in a single launch, for the HBM-bound high-resolution levels.
@@ -187,7 +219,12 @@ typedef struct vqae_config {
     int projection_dim;   /* 0: EMAVectorQuantizer; >0: ProjectedEMAVectorQuantizer2d (vq.py:157-192) */
     float commitment_cost;
     int compute_dtype;    /* VQAE_DT_F32 (default) or autocast bf16 / f16 */
+    int block_kind;       /* VQAE_BLOCK_FIXUP (default) | VQAE_BLOCK_MBCONV (conf/model/{encoder,decoder}/efficientnetv2.yaml) */
+    int expand_ratio;     /* MBConv: mbconv.yaml:32 (4) */
+    int se_divisor;       /* MBConv: layers/misc/se.yaml:5 (4) */
+    float bn_eps;         /* MBConv: layers/misc/batchnorm2d.yaml:4 (1e-5) */
 } vqae_config;
+enum { VQAE_BLOCK_FIXUP = 0, VQAE_BLOCK_MBCONV = 1 };
 
 /* One named fp32 host tensor, named as in the reference's state_dict, e.g.
  * "encoder.pre_enc_layers.0.7.branch_conv2.weight" with PyTorch shapes ([cout][cin][k][k], (1,) ...). */

@@ -154,9 +154,34 @@ def fixup_conf(n_layers):
     }
 
 
+def mbconv_conf(spec):
+    # conf/model/layers/conv_block/mbconv.yaml (+ activation/silu.yaml, misc/se.yaml, misc/batchnorm2d.yaml)
+    proj = lambda: _conv(1, bias=False)                                        # proj2d.yaml
+    down = lambda: _conv(2, stride=2, bias=False, padding_mode="circular")     # down2d.yaml
+    same = lambda: _conv(3, padding=1, bias=False, padding_mode="circular")    # same2d.yaml / out2d.yaml
+    up = lambda: {"_target_": "torch.nn.ConvTranspose2d", "in_channels": None, "out_channels": None,   # up2d.yaml
+                  "kernel_size": 2, "stride": 2, "padding": 0, "output_padding": 0, "groups": 1, "bias": False,
+                  "dilation": 1, "padding_mode": "zeros"}
+    return {
+        "_target_": "vq_ae.layers.conv_block.MBConv", "_recursive_": False,
+        "in_channels": None, "out_channels": None, "mode": None, "expand_ratio": spec.expand_ratio,
+        "activation_conf": {"_target_": "torch.nn.SiLU"},
+        "se_conf": {"_target_": "vq_ae.layers.misc.SELayer", "in_channels": None, "out_channels": None,
+                    "bottleneck_divisor": spec.se_divisor},
+        "batchnorm_conf": {"_target_": "torch.nn.BatchNorm2d", "num_features": None, "eps": 1e-05, "momentum": 0.1,
+                           "affine": True, "track_running_stats": True},
+        "conv_conf": {
+            "down": {"branch_conv1": proj(), "branch_conv2": down(), "branch_conv3": proj(), "skip_conv": down()},
+            "up": {"branch_conv1": proj(), "branch_conv2": up(), "branch_conv3": proj(), "skip_conv": up()},
+            "same": {"branch_conv1": proj(), "branch_conv2": same(), "branch_conv3": proj(), "skip_conv": proj()},
+            "out": {"branch_conv1": proj(), "branch_conv2": same(), "branch_conv3": proj(), "skip_conv": same()},
+        },
+    }
+
+
 def vqae_conf(spec):
     """Nested dict equal to what Hydra composes from conf/model/vq_ae.yaml for `spec`."""
-    fx = fixup_conf(spec.n_layers)
+    fx = mbconv_conf(spec) if getattr(spec, "block", "fixup") == "mbconv" else fixup_conf(spec.n_layers)
     if spec.projection_dim > 0:
         vq = {"_target_": "vq_ae.layers.vq.ProjectedEMAVectorQuantizer2d", "num_embeddings": spec.num_embeddings,
               "embedding_dim": spec.channels, "commitment_cost": spec.commitment_cost, "decay": spec.decay,
@@ -206,7 +231,8 @@ def build_reference_model(spec, params):
     from vq_ae.model import VQAE  # noqa: the reference, unmodified
     model = VQAE(**vqae_conf(spec))
     sd = model.state_dict()
-    missing = [k for k in sd if k not in params and not k.endswith(("embed_avg", "cluster_size", "first_pass"))]
+    missing = [k for k in sd if k not in params
+               and not k.endswith(("embed_avg", "cluster_size", "first_pass", "num_batches_tracked"))]
     assert not missing, missing
     extra = [k for k in params if k not in sd]
     assert not extra, extra
@@ -215,6 +241,9 @@ def build_reference_model(spec, params):
     full[vq + "embed_avg"] = params[vq + "embed"].clone()
     full[vq + "cluster_size"] = torch.zeros(spec.num_embeddings)
     full[vq + "first_pass"] = torch.as_tensor(0)
+    for k in sd:
+        if k.endswith("num_batches_tracked"):
+            full[k] = torch.as_tensor(1)
     for k, v in full.items():
         assert tuple(sd[k].shape) == tuple(v.shape), (k, sd[k].shape, v.shape)
     model.load_state_dict(full)

@@ -278,7 +278,7 @@ def gen_ema():
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="vq,tiny,tinyP,B,A,C,driver,ema,autocast")
+    ap.add_argument("--only", default="vq,tiny,tinyP,B,A,C,driver,ema,autocast,mbconv")
     args = ap.parse_args()
     todo = args.only.split(",")
     torch.manual_seed(0)
@@ -301,6 +301,10 @@ if __name__ == "__main__":
         gen_model_autocast("B", 2, 256, torch.bfloat16, "bf16")
         gen_model_autocast("A", 2, 512, torch.bfloat16, "bf16")      # BASELINE config #3
         gen_model_autocast("C", 1, 256, torch.float16, "f16")        # BASELINE config #4
+    if "mbconv" in todo:
+        print("G8 MBConv / EfficientNetV2 variant")
+        gen_model("tinyM", 2, 32, True)
+        gen_model("BM", 2, 256, False)
     if "driver" in todo:
         print("G5 driver"); gen_driver()
     if "ema" in todo:

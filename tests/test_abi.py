@@ -58,14 +58,14 @@ def test_ops_refuse_cpu_tensors(amd):
 def test_state_dict_names_match_reference(amd, oracle):
     """The module mirrors expose exactly the reference's state-dict names/shapes."""
     from vqae_amd.model import VQAE
-    for name in ("tiny", "tinyP"):
+    for name in ("tiny", "tinyP", "tinyM"):
         m = VQAE.from_spec(amd.SPECS[name])
         sd = {k: tuple(v.shape) for k, v in m.state_dict().items()}
         ref = oracle.param_shapes(oracle.SPECS[name])
         for k, shp in ref.items():
             assert sd[k] == tuple(shp), k
         extra = set(sd) - set(ref)
-        assert all(k.endswith(("embed_avg", "cluster_size", "first_pass")) for k in extra), extra
+        assert all(k.endswith(("embed_avg", "cluster_size", "first_pass", "num_batches_tracked")) for k in extra), extra
 
 
 def test_reference_error_types(amd):

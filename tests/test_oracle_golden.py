@@ -37,11 +37,14 @@ def test_vq_numpy_crosscheck(oracle):
     assert np.array_equal(oracle.vq_argmin_p4_numpy(z.numpy(), embed.numpy()), idx.numpy())
 
 
-@pytest.mark.parametrize("name", ["tiny", "tinyP"])
+@pytest.mark.parametrize("name", ["tiny", "tinyP", "tinyM"])
 def test_model_taps_match_reference_fixture(oracle, name):
     g = load_golden(f"model_{name}")
     spec = oracle.SPECS[name]
-    assert ast.literal_eval(str(g["spec"])) == spec.to_dict()
+    fix, d = ast.literal_eval(str(g["spec"])), spec.to_dict()
+    assert all(d[k] == v for k, v in fix.items())
+    # fields added after a fixture was written must be at their defaults for that fixture's model
+    assert all(d[k] == getattr(oracle.VQAESpec(), k) for k in d.keys() - fix.keys())
     p = oracle.make_params(spec, 0)
     p["encoder.vq_layers.0.embed"] = torch.from_numpy(g["embed"])
     x = torch.from_numpy(g["x"])
@@ -70,6 +73,26 @@ def test_model_B_matches_reference_fixture(oracle):
     assert float(losses[0]) == float(g["loss"])
     assert np.array_equal(out[:, :, ::16, ::16].numpy(), g["out_sample"])
     assert abs(float(((out - x) ** 2).mean()) - float(g["recon_mse"])) < 1e-6 * float(g["recon_mse"])
+
+
+def test_model_BM_matches_reference_fixture(oracle):
+    """MBConv / EfficientNetV2 variant at cfg-B size (conf/model/{encoder,decoder}/efficientnetv2.yaml): the oracle's
+    eval-mode MBConv restatement reproduces the imported reference exactly."""
+    g = load_golden("model_BM")
+    spec = oracle.SPECS["BM"]
+    p = oracle.make_params(spec, 0)
+    p["encoder.vq_layers.0.embed"] = torch.from_numpy(g["embed"])
+    x = oracle.make_patches(int(g["batch"]), int(g["size"]), 0)
+    taps = {}
+    out, losses = oracle.vqae_forward(x, p, spec, taps)
+    assert np.array_equal(taps["idx"].numpy(), g["idx"].astype(np.int64))
+    assert float(losses[0]) == float(g["loss"])
+    assert np.array_equal(out[:, :, ::16, ::16].numpy(), g["out_sample"])
+
+
+def test_se_hidden_is_make_divisible(oracle):
+    # utils/train_helpers.py:21-24 with divide=True
+    assert [oracle.se_hidden(c, 4) for c in (32, 64, 128, 512, 1024, 6)] == [8, 16, 32, 128, 256, 2]
 
 
 def test_bicubic_explicit_restatement(oracle):

@@ -71,6 +71,34 @@ __device__ __forceinline__ float round_dt(float v, int dt) {
     return v;
 }
 
+// ELU(alpha = 1) = max(v, 0) + min(exp(v) - 1, 0) on the hardware exponential (v_exp_f32, <= 1 ulp): 6 VALU
+// instructions, branch-free.  fp32 MFMA does not co-execute with VALU on gfx950, so every instruction here is paid in
+// matrix-pipe time; the previous range-reduced expm1 polynomial (19 instructions, <= 1.5 ulp relative) cost 2x more.
+// Absolute error <= ~1.2e-7 (one ulp of 1.0) -- the size of the fp32 rounding of the O(1) activations around it;
+// relative error near v -> 0- is not preserved, which no consumer of this path needs (the next op adds an O(0.05) bias).
+// VQAE_ELU_POLY=1 at compile time restores the polynomial.
+__device__ __forceinline__ float elu_act(float v) {
+#ifdef VQAE_ELU_POLY
+    const float x = fmaxf(fminf(v, 0.f), -88.f);
+    const float k = __builtin_rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(k, -0.693145751953125f, x);
+    r = __builtin_fmaf(k, -1.42860682030941723e-06f, r);
+    float p = 1.98412698e-04f;
+    p = __builtin_fmaf(p, r, 1.38888889e-03f);
+    p = __builtin_fmaf(p, r, 8.33333333e-03f);
+    p = __builtin_fmaf(p, r, 4.16666667e-02f);
+    p = __builtin_fmaf(p, r, 1.66666667e-01f);
+    p = __builtin_fmaf(p, r, 0.5f);
+    const float em = __builtin_fmaf(p * r, r, r);
+    const float sc = __builtin_ldexpf(1.0f, (int)k);
+    const float e = __builtin_fmaf(sc, em, sc - 1.0f);
+    return v > 0.f ? v : e;
+#else
+    const float e = __builtin_amdgcn_exp2f(v * 1.44269504088896341f);
+    return fmaxf(v, 0.f) + fminf(e - 1.0f, 0.f);
+#endif
+}
+
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
 

@@ -47,25 +47,7 @@ struct ConvK {
     int m16;                             // 16-bit MFMA engine (dt != 0, cin % 32 == 0, no zero padding)
 };
 
-// ELU(alpha = 1) = v > 0 ? v : expm1(v), branch-free so the Fixup pre-op / epilogue can be scheduled
-// between MFMAs: expm1(x) for x <= 0 as 2^k * expm1(r) + (2^k - 1), x = k ln2 + r, |r| <= ln2/2,
-// expm1(r) by a degree-7 Taylor polynomial (truncation < 1e-8 relative): <= ~1.5 ulp of the result.
-__device__ __forceinline__ float elu1(float v) {
-    const float x = fmaxf(fminf(v, 0.f), -88.f);
-    const float k = __builtin_rintf(x * 1.44269504088896341f);
-    float r = __builtin_fmaf(k, -0.693145751953125f, x);
-    r = __builtin_fmaf(k, -1.42860682030941723e-06f, r);
-    float p = 1.98412698e-04f;
-    p = __builtin_fmaf(p, r, 1.38888889e-03f);
-    p = __builtin_fmaf(p, r, 8.33333333e-03f);
-    p = __builtin_fmaf(p, r, 4.16666667e-02f);
-    p = __builtin_fmaf(p, r, 1.66666667e-01f);
-    p = __builtin_fmaf(p, r, 0.5f);
-    const float em = __builtin_fmaf(p * r, r, r);
-    const float sc = __builtin_ldexpf(1.0f, (int)k);
-    const float e = __builtin_fmaf(sc, em, sc - 1.0f);
-    return v > 0.f ? v : e;
-}
+using vqae::elu_act;                     // ELU(alpha = 1), branch-free (common.h)
 
 // ------------------------------------------------------------------------------------------------
 // fp32 MFMA and VALU instructions do not co-execute on gfx950 (SQ_VALU_MFMA_COEXEC_CYCLES = 0 for this
@@ -283,7 +265,7 @@ void conv_mfma_kernel(const ConvK p) {
                 v = v + p.pre_a;
                 if (PRE == VQAE_PRE_BIAS_ELU_BIAS) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = elu1(v[e]) + p.pre_b;
+                    for (int e = 0; e < 4; ++e) v[e] = elu_act(v[e]) + p.pre_b;
                 }
             }
             if (PADZ) { if ((raz >> i) & 1u) v = (f32x4)(0.f); }
@@ -463,7 +445,7 @@ void conv_mfma_kernel(const ConvK p) {
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)           // conv2 output cast, fp32 activation, conv3 input cast
-                    acc[mi][ni][r] = rnd(elu1(rnd(acc[mi][ni][r]) + p.act_a) + p.act_b);
+                    acc[mi][ni][r] = rnd(elu_act(rnd(acc[mi][ni][r]) + p.act_a) + p.act_b);
         __syncthreads();                                    // every wave is done with the last K-step's tiles
         acc_to_lds();
         __syncthreads();
@@ -489,7 +471,7 @@ void conv_mfma_kernel(const ConvK p) {
                     t = t + p.t_b4;
                     t = t + res[r];
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), o_rsrc, base + ((r & 3) + 8 * (r >> 2)) * (CC * 4), 0, 0);
-                    if (TAIL == 2) acc[mi][ni][r] = rnd(elu1(t + p.n_b1a) + p.n_b1b);     // next block's conv1 pre-op
+                    if (TAIL == 2) acc[mi][ni][r] = rnd(elu_act(t + p.n_b1a) + p.n_b1b);     // next block's conv1 pre-op
                 }
             }
         if constexpr (TAIL == 2) {
@@ -506,7 +488,7 @@ void conv_mfma_kernel(const ConvK p) {
                     const unsigned base = (unsigned)((wm * MI * 32 + mi * 32 + 4 * hh) * (CC * 4) + (wn * NI * 32 + ni * 32 + li) * 4);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float t = elu1(rnd(acc[mi][ni][r]) + p.n_b2a) + p.n_b2b;
+                        const float t = elu_act(rnd(acc[mi][ni][r]) + p.n_b2a) + p.n_b2b;
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), t_rsrc, base + ((r & 3) + 8 * (r >> 2)) * (CC * 4), 0, 0);
                     }
                 }
@@ -551,7 +533,7 @@ void conv_mfma_kernel(const ConvK p) {
                 else if (p.has_bias_s) { t = t + p.bias_s; }
                 if (p.residual) t = t + res[r];
                 if (p.has_act == VQAE_ACT_SILU) t = t / (1.0f + expf(-t));
-                else if (p.has_act) t = elu1(t + p.act_a) + p.act_b;
+                else if (p.has_act) t = elu_act(t + p.act_a) + p.act_b;
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), y_rsrc, base + ((r & 3) + 8 * (r >> 2)) * row_bytes, 0, 0);
             }
         }

@@ -1,0 +1,341 @@
+// Winograd F(2x2, 3x3) form of the trunk Fixup block (C = 128 channels at 32-wide code-grid resolution, fp32):
+//   conv2 (3x3 circular, conv_block.py:208)  as  Y = A^T [ sum_c (G g G^T) .* (B^T d B) ] A
+// followed, in the same workgroup, by the block's conv3 (+ scale / bias4 / residual) and the NEXT block's conv1 --
+// the same fusion as conv_mfma.hip's TAIL, whose tail this kernel repeats.
+//
+// Why: fp32 MFMA is the roofline of this path (157.3 TFLOP/s) and the 3x3 conv is 9/11 of a trunk block's matrix
+// work.  F(2x2, 3x3) needs 16 multiplies per 2x2 output tile and channel pair instead of 36: the 3x3 becomes 16
+// independent [tiles x 128] x [128 x 128] GEMMs, 2.25x fewer MFMAs (K_eff = 512 instead of 1152 per output pixel).
+// The transforms are additions only (B^T, A^T have entries 0, +-1; G's halves are folded into the pre-transformed
+// weights on the host), a few VALU instructions per element.  Result differs from the direct form by fp32 rounding
+// only (measured in tests/test_model_gpu.py::test_winograd_trunk_equals_direct).
+//
+// Work split.  A 256-thread workgroup owns 128 output pixels = 4 image rows x 32 columns = 32 Winograd tiles
+// (2 tile rows x 16 tile columns).  Wave w owns output channels [32w, 32w + 32).  The 4x4 transformed domain is
+// walked one row xi at a time (4 passes):
+//   transform  V_xi[nu][tile][c] = (B^T d B)[xi][nu], nu = 0..3, for all 128 input channels -> LDS (4 x 32 x 132 floats);
+//              the input rows come straight from global/L2 (t1 of the block, written by the previous launch)
+//   GEMM       acc[nu] (32 tiles x 32 channels, one 32x32 MFMA tile) += V_xi[nu] x U[xi, nu]^T over K = 128:
+//              A fragments from LDS, B fragments (pre-transformed weights, 1 MiB per layer, L2-resident) from global
+//   fold       Y[a][b] += A^T[a][xi] * A^T[b][nu] * acc   in registers, right after each nu's K loop: the lane that holds
+//              (tile, channel) of one (xi, nu) product holds it for all of them
+// so only one 16-register accumulator + 4 x 16 output registers are live and two workgroups fit a CU; while one
+// transforms, the other one's MFMAs run.  Then t2 = ELU(Y + b3a) + b3b goes to LDS as the [128 px][132] A operand of
+// the conv3 / next-conv1 tails.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+using vqae::elu_act;
+
+struct WinoK {
+    const float* __restrict__ t1;        // [M][128] conv2 input (= ELU(conv1(.) + b2a) + b2b)
+    const float* __restrict__ U;         // [16][128 n][128 k] G g G^T
+    const float* __restrict__ w3;        // packed [128][128]
+    const float* __restrict__ w1n;       // packed [128][128] of the next block's conv1 (TAIL == 2)
+    float* xio;                          // [M][128] residual stream, updated in place
+    float* y2;                           // [M][128] next block's t1 (TAIL == 2)
+    int H, M;                            // image rows (W = 32); M = B * H * 32
+    float act_a, act_b, t_scale, t_b4, n_b1a, n_b1b, n_b2a, n_b2b;
+};
+
+constexpr int CC = 128;                  // channels
+constexpr int LDT = CC + 4;              // LDS row stride (floats): conflict-free ds_read_b128 fragments
+constexpr int BPF = 8;                   // B-fragment prefetch distance (k-slices)
+
+template <int TAIL>
+__global__ __launch_bounds__(256, 2)
+void wino_trunk_kernel(const WinoK p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // V[4][32][LDT]  /  T[128][LDT]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, hh = lane >> 5;
+
+    // XCD-contiguous tile order (as conv_mfma.hip): neighbouring row groups of an image share an L2
+    int tile_m;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        tile_m = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int m0 = tile_m * 128;
+    const int hw = p.H * 32;
+    const int img = m0 / hw;
+    const int row0 = (m0 - img * hw) >> 5;                          // first image row of this workgroup (multiple of 4)
+    const float* const xim = p.t1 + (int64_t)img * hw * CC;
+
+    // ---- transform geometry: thread -> channel group cg, tile column tj0 (+8 for odd items), tile rows 0 / 1 -------
+    const int cg = tid & 31;
+    const int tj0 = tid >> 5;                                        // 0..7
+    int coff[2][4], roff[2][4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = (2 * (tj0 + 8 * s) - 1 + j) & 31;          // circular in x
+            coff[s][j] = c * CC + 4 * cg;
+            int r = row0 + 2 * s - 1 + j;                            // tile row s: input rows row0 + 2s - 1 .. + 2
+            r = r < 0 ? r + p.H : (r >= p.H ? r - p.H : r);          // circular in y
+            roff[s][j] = r * 32 * CC;
+        }
+    }
+
+    const float* const ub = p.U + (int64_t)(32 * wave + li) * CC + 4 * hh;       // this lane's B row, + pos * 128*128
+    const float* const af = lds + li * LDT + 4 * hh;                               // A fragment base, + nu * 32*LDT
+
+    f32x16 y00, y01, y10, y11;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { y00[r] = 0.f; y01[r] = 0.f; y10[r] = 0.f; y11[r] = 0.f; }
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi) {
+        // ---- transform row xi of B^T d B for the 32 tiles x 128 channels -> V[nu][tile][c] -------------------------
+        // B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+        const int ra = xi == 0 ? 0 : (xi == 2 ? 2 : 1);              // row combination: d[ra] (+|-) d[rb]
+        const int rb = xi == 0 ? 2 : (xi == 1 ? 2 : (xi == 2 ? 1 : 3));
+        const bool plus = xi == 1;
+        f32x4 v[4][4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int s_c = it & 1, s_r = it >> 1;                    // tile column set, tile row
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(xim + roff[s_r][ra] + coff[s_c][j]);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(xim + roff[s_r][rb] + coff[s_c][j]);
+                v[it][j] = plus ? a + b : a - b;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (xi > 0) __syncthreads();                                  // every wave is done with V of pass xi - 1
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int tile = (it >> 1) * 16 + tj0 + 8 * (it & 1);
+            float* dst = lds + tile * LDT + 4 * cg;
+            *reinterpret_cast<f32x4*>(dst + 0 * 32 * LDT) = v[it][0] - v[it][2];
+            *reinterpret_cast<f32x4*>(dst + 1 * 32 * LDT) = v[it][1] + v[it][2];
+            *reinterpret_cast<f32x4*>(dst + 2 * 32 * LDT) = v[it][2] - v[it][1];
+            *reinterpret_cast<f32x4*>(dst + 3 * 32 * LDT) = v[it][1] - v[it][3];
+        }
+
+        // ---- GEMM: acc[nu] = V[nu] x U[xi, nu]^T, 64 steps of one k-slice (8 channels) each -----------------------
+        const float* const ux = ub + (int64_t)(4 * xi) * CC * CC;
+        f32x4 bq[BPF];
+#pragma unroll
+        for (int s = 0; s < BPF; ++s)                                  // first B fragments: in flight across the barrier
+            bq[s] = *reinterpret_cast<const f32x4*>(ux + (s >> 4) * CC * CC + 8 * (s & 15));
+        __syncthreads();
+        f32x4 aq[2];
+        aq[0] = *reinterpret_cast<const f32x4*>(af);
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) {
+            f32x16 acc;                                               // one accumulator live at a time (register budget)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int s = 16 * nu + u;
+                if (s + 1 < 64)
+                    aq[(s + 1) & 1] = *reinterpret_cast<const f32x4*>(af + ((s + 1) >> 4) * 32 * LDT + 8 * ((s + 1) & 15));
+                const f32x4 b = bq[s % BPF];
+                if (s + BPF < 64)
+                    bq[s % BPF] = *reinterpret_cast<const f32x4*>(ux + ((s + BPF) >> 4) * CC * CC + 8 * ((s + BPF) & 15));
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s & 1][r], b[r], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);                    // keep the prefetch distances as written (register budget)
+            }
+            // fold: Y[a][b] += A^T[a][xi] * A^T[b][nu] * acc,  A^T = [1 1 1 0; 0 1 -1 -1]
+            const int ca0 = xi <= 2 ? 1 : 0, ca1 = xi == 0 ? 0 : (xi == 1 ? 1 : -1);
+            const int cb0 = nu <= 2 ? 1 : 0, cb1 = nu == 0 ? 0 : (nu == 1 ? 1 : -1);
+            if (ca0 * cb0 != 0) y00 = y00 + acc;
+            if (ca0 * cb1 == 1) y01 = y01 + acc; else if (ca0 * cb1 == -1) y01 = y01 - acc;
+            if (ca1 * cb0 == 1) y10 = y10 + acc; else if (ca1 * cb0 == -1) y10 = y10 - acc;
+            if (ca1 * cb1 == 1) y11 = y11 + acc; else if (ca1 * cb1 == -1) y11 = y11 - acc;
+            // pin the fold here: left to itself the compiler defers these adds to the end of the kernel and spills
+            // every (xi, nu) accumulator to scratch meanwhile
+            asm volatile("" : "+v"(y00), "+v"(y01), "+v"(y10), "+v"(y11));
+        }
+    }
+
+    // ---- t2 = ELU(conv2 + b3a) + b3b -> T[pixel][channel] (C/D layout: tile = (r&3) + 8*(r>>2) + 4*hh, channel = li)
+    __syncthreads();                                                  // every wave is done with V of pass 3
+    float* const T = lds;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int tile = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const int px = (2 * (tile >> 4)) * 32 + 2 * (tile & 15);     // top-left pixel of the 2x2 output tile
+        float* d = T + px * LDT + 32 * wave + li;
+        d[0] = elu_act(y00[r] + p.act_a) + p.act_b;
+        d[LDT] = elu_act(y01[r] + p.act_a) + p.act_b;
+        d[32 * LDT] = elu_act(y10[r] + p.act_a) + p.act_b;
+        d[33 * LDT] = elu_act(y11[r] + p.act_a) + p.act_b;
+    }
+    __syncthreads();
+
+    // ---- tails (as conv_mfma.hip TAIL): 2 x 2 waves over the 128 x 128 tile, B fragments straight from L2 ----------
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[2][2];
+    auto gemm_tail = [&](const float* __restrict__ wsrc) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        const float* a0 = T + (wm * 64 + li) * LDT + 4 * hh;
+        const float* b0 = wsrc + (wn * 64 + li) * CC + 4 * hh;
+        f32x4 bt[2][4][2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) bt[0][u][ni] = *reinterpret_cast<const f32x4*>(b0 + ni * 32 * CC + 8 * u);
+#pragma unroll
+        for (int ug = 0; ug < 4; ++ug) {
+            if (ug + 1 < 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        bt[(ug + 1) & 1][u][ni] = *reinterpret_cast<const f32x4*>(b0 + ni * 32 * CC + 8 * (4 * (ug + 1) + u));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                f32x4 a[2];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(a0 + mi * 32 * LDT + 8 * (4 * ug + u));
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][r], bt[ug & 1][u][ni][r], acc[mi][ni], 0, 0, 0);
+            }
+        }
+    };
+    auto acc_to_lds = [&]() {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    T[(wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * LDT + wn * 64 + ni * 32 + li] = acc[mi][ni][r];
+    };
+
+    gemm_tail(p.w3);                                                  // conv3
+    const unsigned range = 128u * CC * 4u;                            // M % 128 == 0: whole tiles only
+    const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.xio + (int64_t)m0 * CC, 0, (int)range, 0x00020000);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const unsigned base = (unsigned)((wm * 64 + mi * 32 + 4 * hh) * (CC * 4) + (wn * 64 + ni * 32 + li) * 4);
+            float res[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(o_rsrc, base + ((r & 3) + 8 * (r >> 2)) * (CC * 4), 0, 0));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float t = acc[mi][ni][r] * p.t_scale;                 // out = conv3 * scale + bias4 + x, in place
+                t = t + p.t_b4;
+                t = t + res[r];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), o_rsrc, base + ((r & 3) + 8 * (r >> 2)) * (CC * 4), 0, 0);
+                if (TAIL == 2) acc[mi][ni][r] = elu_act(t + p.n_b1a) + p.n_b1b;      // next block's conv1 pre-op
+            }
+        }
+    if constexpr (TAIL == 2) {
+        __syncthreads();                                              // conv3 finished reading T
+        acc_to_lds();
+        __syncthreads();
+        gemm_tail(p.w1n);                                             // next block's conv1
+        const __amdgpu_buffer_rsrc_t t_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y2 + (int64_t)m0 * CC, 0, (int)range, 0x00020000);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const unsigned base = (unsigned)((wm * 64 + mi * 32 + 4 * hh) * (CC * 4) + (wn * 64 + ni * 32 + li) * 4);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float t = elu_act(acc[mi][ni][r] + p.n_b2a) + p.n_b2b;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), t_rsrc, base + ((r & 3) + 8 * (r >> 2)) * (CC * 4), 0, 0);
+                }
+            }
+    }
+}
+
+// U[xi*4 + nu][n][k] = (G g G^T)[xi][nu] for g = w[n][k][3][3];  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+__global__ void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;              // over n * 128 + k
+    if (i >= CC * CC) return;
+    float g[3][3], t[4][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) g[a][b] = w[(int64_t)i * 9 + a * 3 + b];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        t[0][b] = g[0][b];
+        t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+        t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+        t[3][b] = g[2][b];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        U[(int64_t)(a * 4 + 0) * CC * CC + i] = t[a][0];
+        U[(int64_t)(a * 4 + 1) * CC * CC + i] = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
+        U[(int64_t)(a * 4 + 2) * CC * CC + i] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
+        U[(int64_t)(a * 4 + 3) * CC * CC + i] = t[a][2];
+    }
+}
+
+}  // namespace
+
+namespace vqae {
+
+bool wino_trunk_supported(int c, int h, int w) { return c == CC && w == 32 && h >= 4 && h % 4 == 0; }
+
+size_t wino_weight_floats() { return (size_t)16 * CC * CC; }
+
+// w_oihw_dev [128][128][3][3] (PyTorch layout, device) -> U_dev [16][128][128]
+int wino_transform_weight(const float* w_oihw_dev, float* U_dev, hipStream_t stream) {
+    wino_weight_kernel<<<CC * CC / 256, 256, 0, stream>>>(w_oihw_dev, U_dev);
+    VQAE_LAUNCH_CHECK();
+    return VQAE_OK;
+}
+
+// Same contract as conv_trunk_tail (conv_mfma.hip) for C = 128, W = 32, fp32: t1 -> xio in place (+ t1_next).
+int wino_trunk_tail(const float* t1, const float* U, const float* w3, float act_a, float act_b, float t_scale, float t_b4,
+                    float* xio, const float* w1n, float n_b1a, float n_b1b, float n_b2a, float n_b2b, float* t1_next,
+                    int batch, int h, hipStream_t stream) {
+    if (batch == 0) return VQAE_OK;
+    VQAE_REQUIRE(t1 && U && w3 && xio && (!w1n || t1_next), VQAE_ERR_INVALID, "wino_trunk_tail: null pointer");
+    VQAE_REQUIRE(wino_trunk_supported(CC, h, 32), VQAE_ERR_UNSUPPORTED, "wino_trunk_tail: H = %d", h);
+    const int64_t M = (int64_t)batch * h * 32;
+    VQAE_REQUIRE(M < (1ll << 31) - 256, VQAE_ERR_UNSUPPORTED, "wino_trunk_tail: too many pixels");
+    WinoK k;
+    k.t1 = t1; k.U = U; k.w3 = w3; k.w1n = w1n; k.xio = xio; k.y2 = t1_next;
+    k.H = h; k.M = (int)M;
+    k.act_a = act_a; k.act_b = act_b; k.t_scale = t_scale; k.t_b4 = t_b4;
+    k.n_b1a = n_b1a; k.n_b1b = n_b1b; k.n_b2a = n_b2a; k.n_b2b = n_b2b;
+    constexpr int lds_bytes = 128 * LDT * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)wino_trunk_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)wino_trunk_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        attr_set = true;
+    }
+    const unsigned grid = (unsigned)(M / 128);
+    // executed matrix work: 16 GEMMs of K = 128 per 4 output pixels (K_eff = 512 per pixel) + the 1x1 tails
+    const double flops = 2.0 * (double)M * CC * (4.0 * CC + CC + (w1n ? CC : 0));
+    ProfScope prof(PROF_CONV3X3_TRUNK, stream, flops);
+    if (w1n) wino_trunk_kernel<2><<<grid, 256, lds_bytes, stream>>>(k);
+    else wino_trunk_kernel<1><<<grid, 256, lds_bytes, stream>>>(k);
+    prof.done();
+    VQAE_LAUNCH_CHECK();
+    return VQAE_OK;
+}
+
+}  // namespace vqae

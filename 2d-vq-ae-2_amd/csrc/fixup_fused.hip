@@ -33,22 +33,7 @@ struct FusedP {
     int dt;                              // VQAE_DT_*: autocast rounding points
 };
 
-__device__ __forceinline__ float elu1f(float v) {      // see conv_mfma.hip
-    const float x = fmaxf(fminf(v, 0.f), -88.f);
-    const float k = __builtin_rintf(x * 1.44269504088896341f);
-    float r = __builtin_fmaf(k, -0.693145751953125f, x);
-    r = __builtin_fmaf(k, -1.42860682030941723e-06f, r);
-    float p = 1.98412698e-04f;
-    p = __builtin_fmaf(p, r, 1.38888889e-03f);
-    p = __builtin_fmaf(p, r, 8.33333333e-03f);
-    p = __builtin_fmaf(p, r, 4.16666667e-02f);
-    p = __builtin_fmaf(p, r, 1.66666667e-01f);
-    p = __builtin_fmaf(p, r, 0.5f);
-    const float em = __builtin_fmaf(p * r, r, r);
-    const float sc = __builtin_ldexpf(1.0f, (int)k);
-    const float e = __builtin_fmaf(sc, em, sc - 1.0f);
-    return v > 0.f ? v : e;
-}
+using vqae::elu_act;
 
 template <int C, int TH>
 struct FusedCfg {
@@ -132,7 +117,7 @@ void fixup_same_small_kernel(const FusedP p) {
                 for (int u = 0; u < C / 8; ++u) {
                     f32x4 v = a[u] + p.b1a;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = RND(elu1f(v[e]) + p.b1b);
+                    for (int e = 0; e < 4; ++e) v[e] = RND(elu_act(v[e]) + p.b1b);
                     const f32x4 bw = *reinterpret_cast<const f32x4*>(w1f + 8 * u);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[r], bw[r], acc, 0, 0, 0);
@@ -141,7 +126,7 @@ void fixup_same_small_kernel(const FusedP p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                        T1[(32 * g + row) * LDT + li] = RND(elu1f(RND(acc[r]) + p.b2a) + p.b2b);
+                        T1[(32 * g + row) * LDT + li] = RND(elu_act(RND(acc[r]) + p.b2a) + p.b2b);
                     }
                 }
             }
@@ -178,7 +163,7 @@ void fixup_same_small_kernel(const FusedP p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    T1[(ry * 32 + row) * LDT + li] = RND(elu1f(RND(acc2[mt][r]) + p.b3a) + p.b3b);   // t2 over t1
+                    T1[(ry * 32 + row) * LDT + li] = RND(elu_act(RND(acc2[mt][r]) + p.b3a) + p.b3b);   // t2 over t1
                 }
             }
         }
@@ -318,13 +303,13 @@ void fixup_same_tiny_kernel(const FusedP p) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int k = 0; k < KQ; ++k) {
-                    const float av = RND(elu1f(v[k]) + p.b1b);
+                    const float av = RND(elu_act(v[k]) + p.b1b);
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w1v[k], acc, 0, 0, 0);
                 }
                 if (n_ok) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        T1[(16 * g + 4 * q + r) * LDT + li] = RND(elu1f(RND(acc[r]) + p.b2a) + p.b2b);
+                        T1[(16 * g + 4 * q + r) * LDT + li] = RND(elu_act(RND(acc[r]) + p.b2a) + p.b2b);
                 }
             }
         }
@@ -361,7 +346,7 @@ void fixup_same_tiny_kernel(const FusedP p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         T1[((wave + 4 * mt) * 32 + 16 * hf + 4 * q + r) * LDT + li] =
-                            RND(elu1f(RND(acc2[mt][hf][r]) + p.b3a) + p.b3b);
+                            RND(elu_act(RND(acc2[mt][hf][r]) + p.b3a) + p.b3b);
         }
         __syncthreads();
 

@@ -155,6 +155,7 @@ def test_trunk_tail_fusion_equals_unfused(amd, oracle, monkeypatch):
     g = load_golden("model_B")
     spec, p = golden_params(oracle, "B", g)
     x = oracle.make_patches(2, 256, 7).cuda()
+    monkeypatch.setenv("VQAE_NO_WINOGRAD", "1")          # same conv2 arithmetic on both sides: this test is about the fusion
     fused = amd.NativeVQAE(amd.SPECS["B"], p)
     out_f, idx_f, loss_f = fused.forward(x)
     monkeypatch.setenv("VQAE_NO_TRUNK_FUSION", "1")
@@ -164,6 +165,35 @@ def test_trunk_tail_fusion_equals_unfused(amd, oracle, monkeypatch):
     assert torch.equal(idx_f, idx_p)
     assert float((out_f - out_p).abs().max()) <= 1e-4 * float(out_p.abs().max())
     assert abs(float(loss_f) - float(loss_p)) <= 1e-6 * float(loss_p)
+
+
+def test_winograd_trunk_equals_direct(amd, oracle, monkeypatch):
+    """The fp32 trunk blocks (C = 128, 32-wide code grid) run conv2 as Winograd F(2x2, 3x3) (csrc/conv_wino.hip);
+    VQAE_NO_WINOGRAD=1 keeps the direct implicit GEMM.  Same function, different fp32 rounding: the pre-VQ features
+    must agree to ~1e-5 relative after 50 blocks, indices on every row outside the rounding band, the decoder output
+    to <= 1e-5 MSE.  Also at H != W (grid 32 wide, 16 / 64 high) and a batch that is not a multiple of anything."""
+    g = load_golden("model_B")
+    spec, p = golden_params(oracle, "B", g)
+    wino = amd.NativeVQAE(amd.SPECS["B"], p)
+    monkeypatch.setenv("VQAE_NO_WINOGRAD", "1")
+    direct = amd.NativeVQAE(amd.SPECS["B"], p)
+    for (B, H, W) in ((2, 256, 256), (3, 128, 256), (1, 512, 256)):
+        x = oracle.make_patches(B, 512, 11)[:, :, :H, :W].contiguous().cuda()
+        z_w, z_d = wino.encode_features(x), direct.encode_features(x)
+        rel = float((z_w - z_d).abs().max() / z_d.abs().max())
+        out_w, idx_w, loss_w = wino.forward(x)
+        out_d, idx_d, loss_d = direct.forward(x)
+        agree = float((idx_w == idx_d).float().mean())
+        q = direct.encode(x)[0]
+        mse = float(((wino.decode(q) - direct.decode(q)) ** 2).mean())
+        print(f"winograd vs direct {B}x{H}x{W}: z rel err {rel:.2e}, idx agreement {agree:.5f}, decoder mse {mse:.2e}")
+        assert rel <= 5e-5 and agree >= 0.999 and mse <= 1e-6
+        assert abs(float(loss_w) - float(loss_d)) <= 1e-4 * float(loss_d)
+    # the fixture of the reference itself, through the Winograd path (default handle)
+    xg = oracle.make_patches(int(g["batch"]), 256, 0).cuda()
+    _, idx, _ = wino.forward(xg)
+    bad_clear, bad, unclear, n = idx_agreement(idx, g, 2e-4)
+    assert bad_clear == 0 and bad <= max(2, n // 2000), (bad_clear, bad, n)
 
 
 @pytest.mark.parametrize("B,H,W", [(1, 32, 32), (3, 64, 96), (5, 96, 32), (2, 128, 128)])

@@ -43,7 +43,7 @@ struct WinoK {
 
 constexpr int CC = 128;                  // channels
 constexpr int LDT = CC + 4;              // LDS row stride (floats): conflict-free ds_read_b128 fragments
-constexpr int BPF = 8;                   // B-fragment prefetch distance (k-slices)
+constexpr int BPF = 6;                   // B-fragment prefetch distance (k-slices)
 
 template <int TAIL>
 __global__ __launch_bounds__(256, 2)
@@ -86,27 +86,38 @@ void wino_trunk_kernel(const WinoK p) {
     const float* const ub = p.U + (int64_t)(32 * wave + li) * CC + 4 * hh;       // this lane's B row, + pos * 128*128
     const float* const af = lds + li * LDT + 4 * hh;                               // A fragment base, + nu * 32*LDT
 
+    // raw input rows of transform pass xi, requested in two halves (tile row 0 / 1) so that a pass's loads can be in
+    // flight under the previous pass's MFMAs within the register budget: B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+    f32x4 v[4][4], la[2][4], lb[2][4];
+    auto tr_load = [&](int xi, int s_r) {                            // tile row s_r: items (it = 2 * s_r + s_c)
+        const int ra = xi == 0 ? 0 : (xi == 2 ? 2 : 1);              // row combination: d[ra] (+|-) d[rb]
+        const int rb = xi == 0 ? 2 : (xi == 1 ? 2 : (xi == 2 ? 1 : 3));
+#pragma unroll
+        for (int s_c = 0; s_c < 2; ++s_c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                la[s_c][j] = *reinterpret_cast<const f32x4*>(xim + roff[s_r][ra] + coff[s_c][j]);
+                lb[s_c][j] = *reinterpret_cast<const f32x4*>(xim + roff[s_r][rb] + coff[s_c][j]);
+            }
+    };
+    auto tr_combine = [&](int xi, int s_r) {
+#pragma unroll
+        for (int s_c = 0; s_c < 2; ++s_c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                v[2 * s_r + s_c][j] = xi == 1 ? la[s_c][j] + lb[s_c][j] : la[s_c][j] - lb[s_c][j];
+    };
+    tr_load(0, 0);
+    tr_combine(0, 0);
+    tr_load(0, 1);
+    tr_combine(0, 1);
+
     f32x16 y00, y01, y10, y11;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { y00[r] = 0.f; y01[r] = 0.f; y10[r] = 0.f; y11[r] = 0.f; }
 #pragma unroll
     for (int xi = 0; xi < 4; ++xi) {
-        // ---- transform row xi of B^T d B for the 32 tiles x 128 channels -> V[nu][tile][c] -------------------------
-        // B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
-        const int ra = xi == 0 ? 0 : (xi == 2 ? 2 : 1);              // row combination: d[ra] (+|-) d[rb]
-        const int rb = xi == 0 ? 2 : (xi == 1 ? 2 : (xi == 2 ? 1 : 3));
-        const bool plus = xi == 1;
-        f32x4 v[4][4];
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int s_c = it & 1, s_r = it >> 1;                    // tile column set, tile row
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(xim + roff[s_r][ra] + coff[s_c][j]);
-                const f32x4 b = *reinterpret_cast<const f32x4*>(xim + roff[s_r][rb] + coff[s_c][j]);
-                v[it][j] = plus ? a + b : a - b;
-            }
-        }
+        // ---- row xi of B^T d B for the 32 tiles x 128 channels -> V[nu][tile][c] (v holds the row combinations) ----
         __builtin_amdgcn_sched_barrier(0);
         if (xi > 0) __syncthreads();                                  // every wave is done with V of pass xi - 1
 #pragma unroll
@@ -121,15 +132,21 @@ void wino_trunk_kernel(const WinoK p) {
 
         // ---- GEMM: acc[nu] = V[nu] x U[xi, nu]^T, 64 steps of one k-slice (8 channels) each -----------------------
         const float* const ux = ub + (int64_t)(4 * xi) * CC * CC;
+#define WB(s) (((s) >> 4) * CC * CC + 8 * ((s) & 15))
         f32x4 bq[BPF];
 #pragma unroll
         for (int s = 0; s < BPF; ++s)                                  // first B fragments: in flight across the barrier
-            bq[s] = *reinterpret_cast<const f32x4*>(ux + (s >> 4) * CC * CC + 8 * (s & 15));
+            bq[s] = *reinterpret_cast<const f32x4*>(ux + WB(s));
         __syncthreads();
         f32x4 aq[2];
         aq[0] = *reinterpret_cast<const f32x4*>(af);
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu) {
+            if (xi < 3) {                                             // next pass's input rows, under this pass's MFMAs
+                if (nu == 0) tr_load(xi + 1, 0);
+                if (nu == 2) { tr_combine(xi + 1, 0); tr_load(xi + 1, 1); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             f32x16 acc;                                               // one accumulator live at a time (register budget)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -140,10 +157,10 @@ void wino_trunk_kernel(const WinoK p) {
                     aq[(s + 1) & 1] = *reinterpret_cast<const f32x4*>(af + ((s + 1) >> 4) * 32 * LDT + 8 * ((s + 1) & 15));
                 const f32x4 b = bq[s % BPF];
                 if (s + BPF < 64)
-                    bq[s % BPF] = *reinterpret_cast<const f32x4*>(ux + ((s + BPF) >> 4) * CC * CC + 8 * ((s + BPF) & 15));
+                    bq[s % BPF] = *reinterpret_cast<const f32x4*>(ux + WB(s + BPF));
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s & 1][r], b[r], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b[r], aq[s & 1][r], acc, 0, 0, 0);   // D[channel][tile]
                 __builtin_amdgcn_sched_barrier(0);                    // keep the prefetch distances as written (register budget)
             }
             // fold: Y[a][b] += A^T[a][xi] * A^T[b][nu] * acc,  A^T = [1 1 1 0; 0 1 -1 -1]
@@ -157,24 +174,43 @@ void wino_trunk_kernel(const WinoK p) {
             // every (xi, nu) accumulator to scratch meanwhile
             asm volatile("" : "+v"(y00), "+v"(y01), "+v"(y10), "+v"(y11));
         }
+        if (xi < 3) tr_combine(xi + 1, 1);
     }
 
-    // ---- t2 = ELU(conv2 + b3a) + b3b -> T[pixel][channel] (C/D layout: tile = (r&3) + 8*(r>>2) + 4*hh, channel = li)
+    // ---- t2 = ELU(conv2 + b3a) + b3b -> T[pixel][channel].  The MFMAs ran with the weights as the row operand, so a
+    // lane holds tile (lane & 31) and, per register group g = r >> 2, four consecutive channels 8g + 4*hh + (r & 3):
+    // every LDS write below is 128 bits.
     __syncthreads();                                                  // every wave is done with V of pass 3
     float* const T = lds;
+    {
+        const int px = (2 * (li >> 4)) * 32 + 2 * (li & 15);          // top-left pixel of this lane's 2x2 output tile
+        float* const d = T + px * LDT + 32 * wave + 4 * hh;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int tile = (r & 3) + 8 * (r >> 2) + 4 * hh;
-        const int px = (2 * (tile >> 4)) * 32 + 2 * (tile & 15);     // top-left pixel of the 2x2 output tile
-        float* d = T + px * LDT + 32 * wave + li;
-        d[0] = elu_act(y00[r] + p.act_a) + p.act_b;
-        d[LDT] = elu_act(y01[r] + p.act_a) + p.act_b;
-        d[32 * LDT] = elu_act(y10[r] + p.act_a) + p.act_b;
-        d[33 * LDT] = elu_act(y11[r] + p.act_a) + p.act_b;
+        for (int g = 0; g < 4; ++g) {
+            f32x4 o00, o01, o10, o11;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o00[e] = elu_act(y00[4 * g + e] + p.act_a) + p.act_b;
+                o01[e] = elu_act(y01[4 * g + e] + p.act_a) + p.act_b;
+                o10[e] = elu_act(y10[4 * g + e] + p.act_a) + p.act_b;
+                o11[e] = elu_act(y11[4 * g + e] + p.act_a) + p.act_b;
+            }
+            *reinterpret_cast<f32x4*>(d + 8 * g) = o00;
+            *reinterpret_cast<f32x4*>(d + 8 * g + LDT) = o01;
+            *reinterpret_cast<f32x4*>(d + 8 * g + 32 * LDT) = o10;
+            *reinterpret_cast<f32x4*>(d + 8 * g + 33 * LDT) = o11;
+        }
     }
+    // residual rows of this tile in the row-coalesced layout of the epilogue (thread -> channel group cg, pixels
+    // tj0 + 8i): requested before conv3's MFMAs so the HBM/L2 latency is covered by them
+    float* const xrow = p.xio + ((int64_t)m0 + tj0) * CC + 4 * cg;
+    f32x4 res[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) res[i] = *reinterpret_cast<const f32x4*>(xrow + (int64_t)(8 * i) * CC);
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
 
-    // ---- tails (as conv_mfma.hip TAIL): 2 x 2 waves over the 128 x 128 tile, B fragments straight from L2 ----------
+    // ---- tails: 2 x 2 waves over the 128 px x 128 ch tile, weight fragments straight from L2, D[channel][pixel] ------
     const int wm = wave >> 1, wn = wave & 1;
     f32x16 acc[2][2];
     auto gemm_tail = [&](const float* __restrict__ wsrc) {
@@ -211,58 +247,57 @@ void wino_trunk_kernel(const WinoK p) {
                     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                         for (int ni = 0; ni < 2; ++ni)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][r], bt[ug & 1][u][ni][r], acc[mi][ni], 0, 0, 0);
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(bt[ug & 1][u][ni][r], a[mi][r], acc[mi][ni], 0, 0, 0);
             }
         }
     };
-    auto acc_to_lds = [&]() {
+    auto acc_to_lds = [&]() {                                         // D[channel][pixel] -> T[pixel][channel], 128-bit writes
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    T[(wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * LDT + wn * 64 + ni * 32 + li] = acc[mi][ni][r];
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = acc[mi][ni][4 * g + e];
+                    *reinterpret_cast<f32x4*>(T + (wm * 64 + mi * 32 + li) * LDT + wn * 64 + ni * 32 + 8 * g + 4 * hh) = o;
+                }
     };
+    float* const trow = T + tj0 * LDT + 4 * cg;                       // row-coalesced view: + (8 i) rows
 
     gemm_tail(p.w3);                                                  // conv3
-    const unsigned range = 128u * CC * 4u;                            // M % 128 == 0: whole tiles only
-    const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.xio + (int64_t)m0 * CC, 0, (int)range, 0x00020000);
+    __syncthreads();                                                  // every wave is done reading t2
+    acc_to_lds();
+    __syncthreads();
+    // out = conv3 * scale + bias4 + x, in place over the residual stream, whole 512-byte rows per half wave
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+    for (int i = 0; i < 16; ++i) {
+        f32x4 t = *reinterpret_cast<const f32x4*>(trow + 8 * i * LDT);
+        t = t * p.t_scale;
+        t = t + p.t_b4;
+        t = t + res[i];
+        *reinterpret_cast<f32x4*>(xrow + (int64_t)(8 * i) * CC) = t;
+        if (TAIL == 2) {                                              // next block's conv1 pre-op, back into T in place
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const unsigned base = (unsigned)((wm * 64 + mi * 32 + 4 * hh) * (CC * 4) + (wn * 64 + ni * 32 + li) * 4);
-            float res[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(o_rsrc, base + ((r & 3) + 8 * (r >> 2)) * (CC * 4), 0, 0));
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float t = acc[mi][ni][r] * p.t_scale;                 // out = conv3 * scale + bias4 + x, in place
-                t = t + p.t_b4;
-                t = t + res[r];
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), o_rsrc, base + ((r & 3) + 8 * (r >> 2)) * (CC * 4), 0, 0);
-                if (TAIL == 2) acc[mi][ni][r] = elu_act(t + p.n_b1a) + p.n_b1b;      // next block's conv1 pre-op
-            }
+            for (int e = 0; e < 4; ++e) t[e] = elu_act(t[e] + p.n_b1a) + p.n_b1b;
+            *reinterpret_cast<f32x4*>(trow + 8 * i * LDT) = t;
         }
+    }
     if constexpr (TAIL == 2) {
-        __syncthreads();                                              // conv3 finished reading T
-        acc_to_lds();
         __syncthreads();
         gemm_tail(p.w1n);                                             // next block's conv1
-        const __amdgpu_buffer_rsrc_t t_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y2 + (int64_t)m0 * CC, 0, (int)range, 0x00020000);
+        __syncthreads();                                              // every wave is done reading T
+        acc_to_lds();
+        __syncthreads();
+        float* const yrow = p.y2 + ((int64_t)m0 + tj0) * CC + 4 * cg;
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int i = 0; i < 16; ++i) {
+            f32x4 t = *reinterpret_cast<const f32x4*>(trow + 8 * i * LDT);
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                const unsigned base = (unsigned)((wm * 64 + mi * 32 + 4 * hh) * (CC * 4) + (wn * 64 + ni * 32 + li) * 4);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float t = elu_act(acc[mi][ni][r] + p.n_b2a) + p.n_b2b;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), t_rsrc, base + ((r & 3) + 8 * (r >> 2)) * (CC * 4), 0, 0);
-                }
-            }
+            for (int e = 0; e < 4; ++e) t[e] = elu_act(t[e] + p.n_b2a) + p.n_b2b;
+            *reinterpret_cast<f32x4*>(yrow + (int64_t)(8 * i) * CC) = t;
+        }
     }
 }
 

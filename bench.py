@@ -202,7 +202,7 @@ def main():
                                    f"patches -> {zh}x{zh} codes, K={spec.num_embeddings}, D={spec.code_dim}, "
                                    f"{args.mode} forward", "global_batch": world * B,
                        "parallelism": f"patch-sharded x{world}" + (", all-gather of code grids" if world > 1 else "")},
-            "conv_tflops": round(value * flops_patch / 1e12, 2),
+            "conv_tflops_direct_equivalent": round(value * flops_patch / 1e12, 2),
             "recon_mse_vs_input": float(((out - x) ** 2).mean()) if out is not None else None,
             "vq_loss": float(loss),
         }
@@ -213,12 +213,19 @@ def main():
             M = B * zh * zh
             alg = k_work.value / k_n.value                  # algorithmic work per launch, summed by the library
             if args.prof_class == 1:
-                # trunk Fixup block kernel: 3x3 circular conv2 (2*M*128*1152) + fused conv3 and next-block
-                # conv1 tails (2*M*128*128 each); M = B*32*32
-                res["roofline"] = {"kernel": "conv_mfma_kernel<128,32,..> (trunk 3x3 conv2 + fused 1x1 tails)",
+                # trunk Fixup block kernel (csrc/conv_wino.hip when fp32 / C = 128 / 32-wide grid, else conv_mfma.hip
+                # TAIL): conv2 3x3 circular + fused conv3 and next-block conv1 tails, M = B*32*32 pixels per launch.
+                #   direct form:   2*M*128*(1152 + 128 + 128) flop
+                #   Winograd form: 2*M*128*( 512 + 128 + 128) flop EXECUTED on the matrix pipe (F(2x2,3x3): 16 multiplies
+                #                  per 4 outputs) -- `achieved`/`frac` price the executed MFMA work, i.e. real pipe
+                #                  utilisation; `direct_equivalent_tflops` is the same launch priced as a direct conv.
+                direct = 2.0 * M * C * (9 * C + C + C)
+                res["roofline"] = {"kernel": "trunk Fixup block: conv2 3x3 (Winograd F(2x2,3x3) in fp32 at C=128) + fused "
+                                             "conv3 / next-conv1 tails",
                                    "bound": "mfma", "achieved": round(alg / (avg_ms * 1e-3) / 1e12, 2),
                                    "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "traffic": pmc_traffic(1),
-                                   "launches": k_n.value, "avg_ms": round(avg_ms, 4), "alg_flops_per_launch": alg}
+                                   "launches": k_n.value, "avg_ms": round(avg_ms, 4), "alg_flops_per_launch": alg,
+                                   "direct_equivalent_tflops": round(direct / (avg_ms * 1e-3) / 1e12, 2)}
             elif args.prof_class == 2:
                 res["roofline"] = {"kernel": "conv_mfma_kernel<128,32,..> (1x1, trunk)", "bound": "mfma",
                                    "achieved": round(alg / (avg_ms * 1e-3) / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,

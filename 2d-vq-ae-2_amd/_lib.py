@@ -9,7 +9,8 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvqae_hip.so")
+# VQAE_HIP_LIB: developer override to time an alternative build of the same library (kernel experiments)
+LIB_PATH = os.environ.get("VQAE_HIP_LIB") or os.path.join(_HERE, "libvqae_hip.so")
 
 # enums of vqae_hip.h
 LAYOUT_NHWC, LAYOUT_NCHW = 0, 1

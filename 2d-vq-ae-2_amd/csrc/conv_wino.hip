@@ -32,18 +32,27 @@ using vqae::elu_act;
 
 struct WinoK {
     const float* __restrict__ t1;        // [M][128] conv2 input (= ELU(conv1(.) + b2a) + b2b)
-    const float* __restrict__ U;         // [16][128 n][128 k] G g G^T
-    const float* __restrict__ w3;        // packed [128][128]
-    const float* __restrict__ w1n;       // packed [128][128] of the next block's conv1 (TAIL == 2)
+    const float* __restrict__ U;         // G g G^T in fragment order [16 pos][4 n-slices][16 k-slices][64 lanes][4]
+    const float* __restrict__ w3;        // [128][128] in fragment order [4 n-tiles][16 k-slices][64 lanes][4]
+    const float* __restrict__ w1n;       // same, the next block's conv1 (TAIL == 2)
     float* xio;                          // [M][128] residual stream, updated in place
     float* y2;                           // [M][128] next block's t1 (TAIL == 2)
     int H, M;                            // image rows (W = 32); M = B * H * 32
     float act_a, act_b, t_scale, t_b4, n_b1a, n_b1b, n_b2a, n_b2b;
+#ifdef VQAE_WINO_TRACE
+    unsigned long long* trace;           // [wg][4 waves][16] s_memtime stamps (developer build only)
+#endif
 };
+
+#ifdef VQAE_WINO_TRACE
+#define STAMP(i) do { if (lane == 0) p.trace[((int64_t)blockIdx.x * 4 + wave) * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
 
 constexpr int CC = 128;                  // channels
 constexpr int LDT = CC + 4;              // LDS row stride (floats): conflict-free ds_read_b128 fragments
-constexpr int BPF = 6;                   // B-fragment prefetch distance (k-slices)
+constexpr int BPF = 6;                   // weight-fragment prefetch distance (k-slices)                   // B-fragment prefetch distance (k-slices)
 
 template <int TAIL>
 __global__ __launch_bounds__(256, 2)
@@ -83,11 +92,14 @@ void wino_trunk_kernel(const WinoK p) {
         }
     }
 
-    const float* const ub = p.U + (int64_t)(32 * wave + li) * CC + 4 * hh;       // this lane's B row, + pos * 128*128
+    // Weight fragments are stored in the order the MFMA consumes them: one wave-wide 128-bit load = 1 KiB of
+    // consecutive memory (8 cache lines).  Row-major weights would make the same load touch 32 lines, 32 B of each,
+    // and the L1 tag pipe -- one line per cycle -- would cost as much as the MFMAs it feeds.
+    const float* const ub = p.U + (int64_t)wave * (16 * 256) + 4 * lane;          // + pos * 4 * 16 * 256 + u * 256
     const float* const af = lds + li * LDT + 4 * hh;                               // A fragment base, + nu * 32*LDT
 
-    // raw input rows of transform pass xi, requested in two halves (tile row 0 / 1) so that a pass's loads can be in
-    // flight under the previous pass's MFMAs within the register budget: B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+    // raw input rows of transform pass xi, in two halves (tile row 0 / 1) to bound the registers in flight:
+    // B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
     f32x4 v[4][4], la[2][4], lb[2][4];
     auto tr_load = [&](int xi, int s_r) {                            // tile row s_r: items (it = 2 * s_r + s_c)
         const int ra = xi == 0 ? 0 : (xi == 2 ? 2 : 1);              // row combination: d[ra] (+|-) d[rb]
@@ -112,6 +124,22 @@ void wino_trunk_kernel(const WinoK p) {
     tr_load(0, 1);
     tr_combine(0, 1);
 
+    // Tail operands requested while the last pass's MFMAs run.  vmcnt retires in order (stores included), so a load
+    // issued behind a slow one waits for it: the residual rows (HBM) go out after the last weight-fragment load of
+    // the main phase, the first weight fragments of each tail GEMM before the stores of the epilogue in front of it.
+    const int wm = wave >> 1, wn = wave & 1;
+    float* const xrow = p.xio + ((int64_t)m0 + tj0) * CC + 4 * cg;   // row-coalesced view of the tile: + 8 i rows
+    f32x4 res[16];
+    f32x4 bt[2][4][2];
+    auto tail_prefetch = [&](const float* __restrict__ wsrc) {
+        const float* b0 = wsrc + (wn * 2) * (16 * 256) + 4 * lane;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) bt[0][u][ni] = *reinterpret_cast<const f32x4*>(b0 + ni * (16 * 256) + 256 * u);
+    };
+
+    STAMP(0);
     f32x16 y00, y01, y10, y11;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { y00[r] = 0.f; y01[r] = 0.f; y10[r] = 0.f; y11[r] = 0.f; }
@@ -131,22 +159,18 @@ void wino_trunk_kernel(const WinoK p) {
         }
 
         // ---- GEMM: acc[nu] = V[nu] x U[xi, nu]^T, 64 steps of one k-slice (8 channels) each -----------------------
-        const float* const ux = ub + (int64_t)(4 * xi) * CC * CC;
-#define WB(s) (((s) >> 4) * CC * CC + 8 * ((s) & 15))
+        const float* const ux = ub + (int64_t)(4 * xi) * (4 * 16 * 256);
+#define WB(s) (((s) >> 4) * (4 * 16 * 256) + 256 * ((s) & 15))
         f32x4 bq[BPF];
 #pragma unroll
         for (int s = 0; s < BPF; ++s)                                  // first B fragments: in flight across the barrier
             bq[s] = *reinterpret_cast<const f32x4*>(ux + WB(s));
         __syncthreads();
+        STAMP(14 + 4 * xi);                                           // 14,18,22,26: GEMM start of pass xi
         f32x4 aq[2];
         aq[0] = *reinterpret_cast<const f32x4*>(af);
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu) {
-            if (xi < 3) {                                             // next pass's input rows, under this pass's MFMAs
-                if (nu == 0) tr_load(xi + 1, 0);
-                if (nu == 2) { tr_combine(xi + 1, 0); tr_load(xi + 1, 1); }
-                __builtin_amdgcn_sched_barrier(0);
-            }
             f32x16 acc;                                               // one accumulator live at a time (register budget)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -158,6 +182,11 @@ void wino_trunk_kernel(const WinoK p) {
                 const f32x4 b = bq[s % BPF];
                 if (s + BPF < 64)
                     bq[s % BPF] = *reinterpret_cast<const f32x4*>(ux + WB(s + BPF));
+                if (xi == 3 && s == 64 - BPF) {                        // main phase has no more loads to issue
+                    tail_prefetch(p.w3);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) res[i] = *reinterpret_cast<const f32x4*>(xrow + (int64_t)(8 * i) * CC);
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b[r], aq[s & 1][r], acc, 0, 0, 0);   // D[channel][tile]
@@ -173,8 +202,14 @@ void wino_trunk_kernel(const WinoK p) {
             // pin the fold here: left to itself the compiler defers these adds to the end of the kernel and spills
             // every (xi, nu) accumulator to scratch meanwhile
             asm volatile("" : "+v"(y00), "+v"(y01), "+v"(y10), "+v"(y11));
+            if (nu < 3) STAMP(15 + 4 * xi + nu);                      // after nu = 0, 1, 2
         }
-        if (xi < 3) tr_combine(xi + 1, 1);
+        // Next pass's input rows are requested only now.  Requesting them under this pass's MFMAs measured SLOWER
+        // (0.499 vs 0.478 ms per launch), as did a longer weight-fragment prefetch: more loads in flight per CU back
+        // up the vector-memory queue and the in-order wave stalls at issue, MFMAs included.  The partner workgroup of
+        // the CU covers this wait.
+        if (xi < 3) { tr_load(xi + 1, 0); tr_combine(xi + 1, 0); tr_load(xi + 1, 1); tr_combine(xi + 1, 1); }
+        STAMP(1 + xi);
     }
 
     // ---- t2 = ELU(conv2 + b3a) + b3b -> T[pixel][channel].  The MFMAs ran with the weights as the row operand, so a
@@ -201,17 +236,11 @@ void wino_trunk_kernel(const WinoK p) {
             *reinterpret_cast<f32x4*>(d + 8 * g + 33 * LDT) = o11;
         }
     }
-    // residual rows of this tile in the row-coalesced layout of the epilogue (thread -> channel group cg, pixels
-    // tj0 + 8i): requested before conv3's MFMAs so the HBM/L2 latency is covered by them
-    float* const xrow = p.xio + ((int64_t)m0 + tj0) * CC + 4 * cg;
-    f32x4 res[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) res[i] = *reinterpret_cast<const f32x4*>(xrow + (int64_t)(8 * i) * CC);
-    __builtin_amdgcn_sched_barrier(0);
+    STAMP(5);
     __syncthreads();
+    STAMP(6);
 
     // ---- tails: 2 x 2 waves over the 128 px x 128 ch tile, weight fragments straight from L2, D[channel][pixel] ------
-    const int wm = wave >> 1, wn = wave & 1;
     f32x16 acc[2][2];
     auto gemm_tail = [&](const float* __restrict__ wsrc) {
 #pragma unroll
@@ -221,20 +250,15 @@ void wino_trunk_kernel(const WinoK p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
         const float* a0 = T + (wm * 64 + li) * LDT + 4 * hh;
-        const float* b0 = wsrc + (wn * 64 + li) * CC + 4 * hh;
-        f32x4 bt[2][4][2];
+        const float* b0 = wsrc + (wn * 2) * (16 * 256) + 4 * lane;
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) bt[0][u][ni] = *reinterpret_cast<const f32x4*>(b0 + ni * 32 * CC + 8 * u);
-#pragma unroll
-        for (int ug = 0; ug < 4; ++ug) {
+        for (int ug = 0; ug < 4; ++ug) {                              // bt[0] = first 4 k-slices: tail_prefetch()
             if (ug + 1 < 4) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni)
-                        bt[(ug + 1) & 1][u][ni] = *reinterpret_cast<const f32x4*>(b0 + ni * 32 * CC + 8 * (4 * (ug + 1) + u));
+                        bt[(ug + 1) & 1][u][ni] = *reinterpret_cast<const f32x4*>(b0 + ni * (16 * 256) + 256 * (4 * (ug + 1) + u));
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -267,9 +291,12 @@ void wino_trunk_kernel(const WinoK p) {
     float* const trow = T + tj0 * LDT + 4 * cg;                       // row-coalesced view: + (8 i) rows
 
     gemm_tail(p.w3);                                                  // conv3
+    STAMP(7);
+    if (TAIL == 2) tail_prefetch(p.w1n);                              // ahead of the epilogue's stores
     __syncthreads();                                                  // every wave is done reading t2
     acc_to_lds();
     __syncthreads();
+    STAMP(8);
     // out = conv3 * scale + bias4 + x, in place over the residual stream, whole 512-byte rows per half wave
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -284,12 +311,16 @@ void wino_trunk_kernel(const WinoK p) {
             *reinterpret_cast<f32x4*>(trow + 8 * i * LDT) = t;
         }
     }
+    STAMP(9);
     if constexpr (TAIL == 2) {
         __syncthreads();
+        STAMP(10);
         gemm_tail(p.w1n);                                             // next block's conv1
+        STAMP(11);
         __syncthreads();                                              // every wave is done reading T
         acc_to_lds();
         __syncthreads();
+        STAMP(12);
         float* const yrow = p.y2 + ((int64_t)m0 + tj0) * CC + 4 * cg;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -298,10 +329,17 @@ void wino_trunk_kernel(const WinoK p) {
             for (int e = 0; e < 4; ++e) t[e] = elu_act(t[e] + p.n_b2a) + p.n_b2b;
             *reinterpret_cast<f32x4*>(yrow + (int64_t)(8 * i) * CC) = t;
         }
+        STAMP(13);
     }
 }
 
-// U[xi*4 + nu][n][k] = (G g G^T)[xi][nu] for g = w[n][k][3][3];  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+// Fragment order of a [128 n][128 k] matrix: element (n, k) of the 32-row tile n >> 5 and 8-wide k-slice k >> 3 goes to
+// lane (k >> 2 & 1) * 32 + (n & 31), component k & 3 -- what lane (li = n & 31, hh) feeds to MFMA number k & 3 of the slice.
+__device__ __forceinline__ int frag_offset(int n, int k) {
+    return (((n >> 5) * 16 + (k >> 3)) * 64 + ((k >> 2) & 1) * 32 + (n & 31)) * 4 + (k & 3);
+}
+
+// U[xi*4 + nu] = (G g G^T)[xi][nu] for g = w[n][k][3][3];  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
 __global__ void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;              // over n * 128 + k
     if (i >= CC * CC) return;
@@ -317,13 +355,21 @@ __global__ void wino_weight_kernel(const float* __restrict__ w, float* __restric
         t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
         t[3][b] = g[2][b];
     }
+    const int fo = frag_offset(i / CC, i % CC);
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-        U[(int64_t)(a * 4 + 0) * CC * CC + i] = t[a][0];
-        U[(int64_t)(a * 4 + 1) * CC * CC + i] = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
-        U[(int64_t)(a * 4 + 2) * CC * CC + i] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
-        U[(int64_t)(a * 4 + 3) * CC * CC + i] = t[a][2];
+        U[(int64_t)(a * 4 + 0) * CC * CC + fo] = t[a][0];
+        U[(int64_t)(a * 4 + 1) * CC * CC + fo] = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
+        U[(int64_t)(a * 4 + 2) * CC * CC + fo] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
+        U[(int64_t)(a * 4 + 3) * CC * CC + fo] = t[a][2];
     }
+}
+
+// packed [128 n][128 k] (vqae_conv_pack_weight_f32) -> fragment order
+__global__ void frag_weight_kernel(const float* __restrict__ w, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= CC * CC) return;
+    out[frag_offset(i / CC, i % CC)] = w[i];
 }
 
 }  // namespace
@@ -337,6 +383,13 @@ size_t wino_weight_floats() { return (size_t)16 * CC * CC; }
 // w_oihw_dev [128][128][3][3] (PyTorch layout, device) -> U_dev [16][128][128]
 int wino_transform_weight(const float* w_oihw_dev, float* U_dev, hipStream_t stream) {
     wino_weight_kernel<<<CC * CC / 256, 256, 0, stream>>>(w_oihw_dev, U_dev);
+    VQAE_LAUNCH_CHECK();
+    return VQAE_OK;
+}
+
+// packed [128][128] 1x1 weights (device) -> fragment order (device)
+int wino_frag_weight(const float* w_packed_dev, float* out_dev, hipStream_t stream) {
+    frag_weight_kernel<<<CC * CC / 256, 256, 0, stream>>>(w_packed_dev, out_dev);
     VQAE_LAUNCH_CHECK();
     return VQAE_OK;
 }
@@ -366,9 +419,26 @@ int wino_trunk_tail(const float* t1, const float* U, const float* w3, float act_
     // executed matrix work: 16 GEMMs of K = 128 per 4 output pixels (K_eff = 512 per pixel) + the 1x1 tails
     const double flops = 2.0 * (double)M * CC * (4.0 * CC + CC + (w1n ? CC : 0));
     ProfScope prof(PROF_CONV3X3_TRUNK, stream, flops);
+#ifdef VQAE_WINO_TRACE
+    static unsigned long long* trace = nullptr;
+    static int launches = 0;
+    if (!trace) (void)hipMalloc((void**)&trace, (size_t)4096 * 128 * 8);
+    VQAE_REQUIRE(trace && grid <= 4096, VQAE_ERR_UNSUPPORTED, "trace build: grid %u > 4096", grid);
+    k.trace = trace;
+#endif
     if (w1n) wino_trunk_kernel<2><<<grid, 256, lds_bytes, stream>>>(k);
     else wino_trunk_kernel<1><<<grid, 256, lds_bytes, stream>>>(k);
     prof.done();
+#ifdef VQAE_WINO_TRACE
+    if (w1n && grid == 2048 && ++launches == 200) {       // one steady-state launch of the B = 256 bench
+        (void)hipStreamSynchronize(stream);
+        unsigned long long* host = new unsigned long long[(size_t)grid * 128];
+        (void)hipMemcpy(host, trace, (size_t)grid * 128 * 8, hipMemcpyDeviceToHost);
+        FILE* f = fopen("gpurun_out/wino_trace.bin", "wb");
+        if (f) { fwrite(host, 8, (size_t)grid * 128, f); fclose(f); }
+        delete[] host;
+    }
+#endif
     VQAE_LAUNCH_CHECK();
     return VQAE_OK;
 }

@@ -24,6 +24,7 @@ int conv_trunk_tail(const vqae_conv_args* a, const float* t1, const float* w2, c
 bool wino_trunk_supported(int c, int h, int w);
 size_t wino_weight_floats();
 int wino_transform_weight(const float* w_oihw_dev, float* U_dev, hipStream_t stream);
+int wino_frag_weight(const float* w_packed_dev, float* out_dev, hipStream_t stream);
 int wino_trunk_tail(const float* t1, const float* U, const float* w3, float act_a, float act_b, float t_scale, float t_b4,
                     float* xio, const float* w1n, float n_b1a, float n_b1b, float n_b2a, float n_b2b, float* t1_next,
                     int batch, int h, hipStream_t stream);
@@ -87,6 +88,7 @@ struct Block {
     float b1a, b1b, b2a, b2b, b3a, b3b, b4, scale, b1c, b1d;
     float *w1, *w2, *w3, *wskip;          // packed, device
     float* wU = nullptr;                  // Winograd-domain conv2 weights [16][128][128] (fp32 trunk blocks, conv_wino.hip)
+    float *w1f = nullptr, *w3f = nullptr; // conv1 / conv3 weights in MFMA fragment order for that kernel's tails
     // MBConv (conv_block.py:240-321), BatchNorms folded: br = expanded width, w2 = depthwise taps [k*k][br]
     int kind = VQAE_BLOCK_FIXUP, hidden = 0;
     float *bv1 = nullptr, *bv2 = nullptr, *bv3 = nullptr;                        // folded BN shifts
@@ -213,11 +215,18 @@ int load_block(vqae_handle* h, const TensorMap& tm, const std::string& pre, int 
     if ((rc = upload_packed(h, p, b->br, cin, 1, &b->w1))) return rc;
     if ((rc = find(tm, pre + ".branch_conv2.weight", (int64_t)b->br * b->br * k2 * k2, &p))) return rc;
     if ((rc = upload_packed(h, p, b->br, b->br, k2, &b->w2))) return rc;
-    b->wU = nullptr;
-    if (mode == MODE_SAME && cin == 128 && cout == 128 && h->cfg.compute_dtype == VQAE_DT_F32 && h->use_wino)
-        if ((rc = upload_wino(h, p, &b->wU))) return rc;
+    b->wU = b->w1f = b->w3f = nullptr;
+    const bool wino = mode == MODE_SAME && cin == 128 && cout == 128 && h->cfg.compute_dtype == VQAE_DT_F32 && h->use_wino;
+    if (wino && (rc = upload_wino(h, p, &b->wU))) return rc;
     if ((rc = find(tm, pre + ".branch_conv3.weight", (int64_t)cout * b->br, &p))) return rc;
     if ((rc = upload_packed(h, p, cout, b->br, 1, &b->w3))) return rc;
+    if (wino) {
+        void *f1, *f3;
+        if ((rc = dev_alloc(h, 128 * 128 * 4, &f1)) || (rc = dev_alloc(h, 128 * 128 * 4, &f3))) return rc;
+        b->w1f = (float*)f1; b->w3f = (float*)f3;
+        if ((rc = vqae::wino_frag_weight(b->w1, b->w1f, nullptr)) || (rc = vqae::wino_frag_weight(b->w3, b->w3f, nullptr))) return rc;
+        VQAE_HIP_CHECK(hipDeviceSynchronize());
+    }
     if (mode != MODE_SAME) {
         S_(b1c, "bias1c") S_(b1d, "bias1d")
         const int ks = mode == MODE_DOWN ? 2 : 1;
@@ -372,8 +381,8 @@ int run_block(vqae_handle* h, const Block& b, const Block* next, int B, int& H, 
             if ((rc = vqae_conv2d_f32(&c1.a, X, b.w1, nullptr, nullptr, P, st))) return rc;
         }
         const bool chain = next && next->mode == MODE_SAME && next->cin == b.cin && next->cout == b.cin;
-        if (b.wU && g_dt == VQAE_DT_F32 && vqae::wino_trunk_supported(b.cin, H, W)) {
-            if ((rc = vqae::wino_trunk_tail(P, b.wU, b.w3, b.b3a, b.b3b, b.scale, b.b4, X, chain ? next->w1 : nullptr,
+        if (b.wU && g_dt == VQAE_DT_F32 && vqae::wino_trunk_supported(b.cin, H, W) && (!chain || next->w1f)) {
+            if ((rc = vqae::wino_trunk_tail(P, b.wU, b.w3f, b.b3a, b.b3b, b.scale, b.b4, X, chain ? next->w1f : nullptr,
                                             chain ? next->b1a : 0.f, chain ? next->b1b : 0.f, chain ? next->b2a : 0.f,
                                             chain ? next->b2b : 0.f, chain ? Q : nullptr, B, H, st))) return rc;
             if (chain) std::swap(h->buf[1], h->buf[2]);

@@ -1,4 +1,5 @@
-// Winograd F(2x2, 3x3) form of the trunk Fixup block (C = 128 channels at 32-wide code-grid resolution, fp32):
+// Winograd F(2x2, 3x3) form of the trunk Fixup blocks, fp32: C = 128 channels on a 32-wide grid (the code-grid
+// resolution) and C = 64 on a 64-wide grid (the level above it):
 //   conv2 (3x3 circular, conv_block.py:208)  as  Y = A^T [ sum_c (G g G^T) .* (B^T d B) ] A
 // followed, in the same workgroup, by the block's conv3 (+ scale / bias4 / residual) and the NEXT block's conv1 --
 // the same fusion as conv_mfma.hip's TAIL, whose tail this kernel repeats.
@@ -10,9 +11,9 @@
 // weights on the host), a few VALU instructions per element.  Result differs from the direct form by fp32 rounding
 // only (measured in tests/test_model_gpu.py::test_winograd_trunk_equals_direct).
 //
-// Work split.  A 256-thread workgroup owns 128 output pixels = 4 image rows x 32 columns = 32 Winograd tiles
-// (2 tile rows x 16 tile columns).  Wave w owns output channels [32w, 32w + 32).  The 4x4 transformed domain is
-// walked one row xi at a time (4 passes):
+// Work split (written for C = 128; C = 64 in brackets).  A 256-thread workgroup owns 4 image rows = 128 [256] output
+// pixels = 32 [64] Winograd tiles (2 tile rows x 16 [32] tile columns).  A wave owns 32 output channels and 32 tiles:
+// 4 channel slices x 1 tile group [2 x 2].  The 4x4 transformed domain is walked one row xi at a time (4 passes):
 //   transform  V_xi[nu][tile][c] = (B^T d B)[xi][nu], nu = 0..3, for all 128 input channels -> LDS (4 x 32 x 132 floats);
 //              the input rows come straight from global/L2 (t1 of the block, written by the previous launch)
 //   GEMM       acc[nu] (32 tiles x 32 channels, one 32x32 MFMA tile) += V_xi[nu] x U[xi, nu]^T over K = 128:
@@ -31,37 +32,61 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 using vqae::elu_act;
 
 struct WinoK {
-    const float* __restrict__ t1;        // [M][128] conv2 input (= ELU(conv1(.) + b2a) + b2b)
-    const float* __restrict__ U;         // G g G^T in fragment order [16 pos][4 n-slices][16 k-slices][64 lanes][4]
-    const float* __restrict__ w3;        // [128][128] in fragment order [4 n-tiles][16 k-slices][64 lanes][4]
+    const float* __restrict__ t1;        // [M][C] conv2 input (= ELU(conv1(.) + b2a) + b2b)
+    const float* __restrict__ U;         // G g G^T in fragment order [16 pos][C/32 n-tiles][C/8 k-slices][64 lanes][4]
+    const float* __restrict__ w3;        // [C][C] in fragment order [C/32 n-tiles][C/8 k-slices][64 lanes][4]
     const float* __restrict__ w1n;       // same, the next block's conv1 (TAIL == 2)
-    float* xio;                          // [M][128] residual stream, updated in place
-    float* y2;                           // [M][128] next block's t1 (TAIL == 2)
-    int H, M;                            // image rows (W = 32); M = B * H * 32
+    float* xio;                          // [M][C] residual stream, updated in place
+    float* y2;                           // [M][C] next block's t1 (TAIL == 2)
+    int H, M;                            // image rows; M = B * H * W
     float act_a, act_b, t_scale, t_b4, n_b1a, n_b1b, n_b2a, n_b2b;
 #ifdef VQAE_WINO_TRACE
-    unsigned long long* trace;           // [wg][4 waves][16] s_memtime stamps (developer build only)
+    unsigned long long* trace;           // [wg][4 waves][32] s_memtime stamps (developer build only)
 #endif
 };
 
+// Developer aid (off by default): per-phase s_memtime stamps of every wave -> gpurun_out/wino_trace.bin.  It showed that
+// the cost of this kernel's first version sat in the L1 tag pipe (row-major weight fragments), not in HBM or the MFMAs.
 #ifdef VQAE_WINO_TRACE
 #define STAMP(i) do { if (lane == 0) p.trace[((int64_t)blockIdx.x * 4 + wave) * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMP(i) do {} while (0)
 #endif
 
-constexpr int CC = 128;                  // channels
-constexpr int LDT = CC + 4;              // LDS row stride (floats): conflict-free ds_read_b128 fragments
-constexpr int BPF = 6;                   // weight-fragment prefetch distance (k-slices)                   // B-fragment prefetch distance (k-slices)
+constexpr int BPF = 6;                   // weight-fragment prefetch distance (k-slices)
 
-template <int TAIL>
+template <int C> struct WinoCfg {
+    static constexpr int W = C == 128 ? 32 : 64;      // grid width this channel count runs at
+    static constexpr int PX = 4 * W;                   // output pixels per workgroup (4 image rows)
+    static constexpr int TILES = PX / 4;               // 2x2 output tiles per workgroup
+    static constexpr int TC = W / 2;                   // tile columns
+    static constexpr int NS = C / 32;                  // 32-channel slices
+    static constexpr int KS = C / 8;                   // k-slices (8 channels) per GEMM
+    static constexpr int C4 = C / 4;                   // float4 per pixel
+    static constexpr int RP = 256 / C4;                // pixels (or tile columns) covered by one sweep of the 256 threads
+    static constexpr int LDT = C + 4;                  // LDS row stride (floats): conflict-free ds_read_b128 fragments
+    static constexpr int WN = C / 64;                  // tails: waves along the channels (64 each), 4 / WN along the pixels
+    static constexpr int LDS_BYTES = PX * LDT * 4;     // V[4][TILES][LDT] and T[PX][LDT] overlay each other
+};
+
+// Fragment order of a [C n][C k] matrix: element (n, k) of the 32-row tile n >> 5 and 8-wide k-slice k >> 3 goes to
+// lane (k >> 2 & 1) * 32 + (n & 31), component k & 3 -- what lane (li = n & 31, hh) feeds to MFMA number k & 3 of the slice.
+__device__ __forceinline__ int frag_offset(int n, int k, int c) {
+    return (((n >> 5) * (c / 8) + (k >> 3)) * 64 + ((k >> 2) & 1) * 32 + (n & 31)) * 4 + (k & 3);
+}
+
+template <int C, int TAIL>
 __global__ __launch_bounds__(256, 2)
 void wino_trunk_kernel(const WinoK p) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];      // V[4][32][LDT]  /  T[128][LDT]
+    using K = WinoCfg<C>;
+    constexpr int W = K::W, PX = K::PX, TC = K::TC, NS = K::NS, KS = K::KS, C4 = K::C4, RP = K::RP, LDT = K::LDT, WN = K::WN;
+    constexpr int STEPS = 4 * KS;                                    // k-slices per pass (4 nu)
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // V[4][TILES][LDT]  /  T[PX][LDT]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, hh = lane >> 5;
+    const int ns = wave % NS, mt = wave / NS;                        // main phase: channel slice, 32-tile group
 
     // XCD-contiguous tile order (as conv_mfma.hip): neighbouring row groups of an image share an L2
     int tile_m;
@@ -70,33 +95,33 @@ void wino_trunk_kernel(const WinoK p) {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         tile_m = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int m0 = tile_m * 128;
-    const int hw = p.H * 32;
+    const int m0 = tile_m * PX;
+    const int hw = p.H * W;
     const int img = m0 / hw;
-    const int row0 = (m0 - img * hw) >> 5;                          // first image row of this workgroup (multiple of 4)
-    const float* const xim = p.t1 + (int64_t)img * hw * CC;
+    const int row0 = (m0 - img * hw) / W;                            // first image row of this workgroup (multiple of 4)
+    const float* const xim = p.t1 + (int64_t)img * hw * C;
 
-    // ---- transform geometry: thread -> channel group cg, tile column tj0 (+8 for odd items), tile rows 0 / 1 -------
-    const int cg = tid & 31;
-    const int tj0 = tid >> 5;                                        // 0..7
+    // ---- transform geometry: thread -> channel group cg, tile column tj0 (+ RP for odd items), tile rows 0 / 1 -------
+    const int cg = tid % C4;
+    const int tj0 = tid / C4;                                        // 0 .. RP - 1
     int coff[2][4], roff[2][4];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int c = (2 * (tj0 + 8 * s) - 1 + j) & 31;          // circular in x
-            coff[s][j] = c * CC + 4 * cg;
+            const int c = (2 * (tj0 + RP * s) - 1 + j) & (W - 1);    // circular in x
+            coff[s][j] = c * C + 4 * cg;
             int r = row0 + 2 * s - 1 + j;                            // tile row s: input rows row0 + 2s - 1 .. + 2
             r = r < 0 ? r + p.H : (r >= p.H ? r - p.H : r);          // circular in y
-            roff[s][j] = r * 32 * CC;
+            roff[s][j] = r * W * C;
         }
     }
 
     // Weight fragments are stored in the order the MFMA consumes them: one wave-wide 128-bit load = 1 KiB of
     // consecutive memory (8 cache lines).  Row-major weights would make the same load touch 32 lines, 32 B of each,
     // and the L1 tag pipe -- one line per cycle -- would cost as much as the MFMAs it feeds.
-    const float* const ub = p.U + (int64_t)wave * (16 * 256) + 4 * lane;          // + pos * 4 * 16 * 256 + u * 256
-    const float* const af = lds + li * LDT + 4 * hh;                               // A fragment base, + nu * 32*LDT
+    const float* const ub = p.U + (int64_t)ns * (KS * 256) + 4 * lane;            // + pos * C * C + u * 256
+    const float* const af = lds + (mt * 32 + li) * LDT + 4 * hh;                   // A fragment base, + nu * TILES * LDT
 
     // raw input rows of transform pass xi, in two halves (tile row 0 / 1) to bound the registers in flight:
     // B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
@@ -127,16 +152,16 @@ void wino_trunk_kernel(const WinoK p) {
     // Tail operands requested while the last pass's MFMAs run.  vmcnt retires in order (stores included), so a load
     // issued behind a slow one waits for it: the residual rows (HBM) go out after the last weight-fragment load of
     // the main phase, the first weight fragments of each tail GEMM before the stores of the epilogue in front of it.
-    const int wm = wave >> 1, wn = wave & 1;
-    float* const xrow = p.xio + ((int64_t)m0 + tj0) * CC + 4 * cg;   // row-coalesced view of the tile: + 8 i rows
+    const int wm = wave / WN, wn = wave % WN;                        // tails: 64 pixels x 64 channels per wave
+    float* const xrow = p.xio + ((int64_t)m0 + tj0) * C + 4 * cg;    // row-coalesced view of the tile: + RP * i rows
     f32x4 res[16];
     f32x4 bt[2][4][2];
     auto tail_prefetch = [&](const float* __restrict__ wsrc) {
-        const float* b0 = wsrc + (wn * 2) * (16 * 256) + 4 * lane;
+        const float* b0 = wsrc + (wn * 2) * (KS * 256) + 4 * lane;
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) bt[0][u][ni] = *reinterpret_cast<const f32x4*>(b0 + ni * (16 * 256) + 256 * u);
+            for (int ni = 0; ni < 2; ++ni) bt[0][u][ni] = *reinterpret_cast<const f32x4*>(b0 + ni * (KS * 256) + 256 * u);
     };
 
     STAMP(0);
@@ -145,28 +170,28 @@ void wino_trunk_kernel(const WinoK p) {
     for (int r = 0; r < 16; ++r) { y00[r] = 0.f; y01[r] = 0.f; y10[r] = 0.f; y11[r] = 0.f; }
 #pragma unroll
     for (int xi = 0; xi < 4; ++xi) {
-        // ---- row xi of B^T d B for the 32 tiles x 128 channels -> V[nu][tile][c] (v holds the row combinations) ----
+        // ---- row xi of B^T d B for all tiles and channels -> V[nu][tile][c] (v holds the row combinations) ---------
         __builtin_amdgcn_sched_barrier(0);
         if (xi > 0) __syncthreads();                                  // every wave is done with V of pass xi - 1
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const int tile = (it >> 1) * 16 + tj0 + 8 * (it & 1);
+            const int tile = (it >> 1) * TC + tj0 + RP * (it & 1);
             float* dst = lds + tile * LDT + 4 * cg;
-            *reinterpret_cast<f32x4*>(dst + 0 * 32 * LDT) = v[it][0] - v[it][2];
-            *reinterpret_cast<f32x4*>(dst + 1 * 32 * LDT) = v[it][1] + v[it][2];
-            *reinterpret_cast<f32x4*>(dst + 2 * 32 * LDT) = v[it][2] - v[it][1];
-            *reinterpret_cast<f32x4*>(dst + 3 * 32 * LDT) = v[it][1] - v[it][3];
+            *reinterpret_cast<f32x4*>(dst + 0 * K::TILES * LDT) = v[it][0] - v[it][2];
+            *reinterpret_cast<f32x4*>(dst + 1 * K::TILES * LDT) = v[it][1] + v[it][2];
+            *reinterpret_cast<f32x4*>(dst + 2 * K::TILES * LDT) = v[it][2] - v[it][1];
+            *reinterpret_cast<f32x4*>(dst + 3 * K::TILES * LDT) = v[it][1] - v[it][3];
         }
 
-        // ---- GEMM: acc[nu] = V[nu] x U[xi, nu]^T, 64 steps of one k-slice (8 channels) each -----------------------
-        const float* const ux = ub + (int64_t)(4 * xi) * (4 * 16 * 256);
-#define WB(s) (((s) >> 4) * (4 * 16 * 256) + 256 * ((s) & 15))
+        // ---- GEMM: acc = V[nu] x U[xi, nu]^T for nu = 0..3, STEPS steps of one k-slice (8 channels) each -------------
+        const float* const ux = ub + (int64_t)(4 * xi) * (C * C);
+#define WB(s) (((s) / KS) * (C * C) + 256 * ((s) % KS))
         f32x4 bq[BPF];
 #pragma unroll
         for (int s = 0; s < BPF; ++s)                                  // first B fragments: in flight across the barrier
             bq[s] = *reinterpret_cast<const f32x4*>(ux + WB(s));
         __syncthreads();
-        STAMP(14 + 4 * xi);                                           // 14,18,22,26: GEMM start of pass xi
+        STAMP(14 + 4 * xi);
         f32x4 aq[2];
         aq[0] = *reinterpret_cast<const f32x4*>(af);
 #pragma unroll
@@ -175,17 +200,17 @@ void wino_trunk_kernel(const WinoK p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int s = 16 * nu + u;
-                if (s + 1 < 64)
-                    aq[(s + 1) & 1] = *reinterpret_cast<const f32x4*>(af + ((s + 1) >> 4) * 32 * LDT + 8 * ((s + 1) & 15));
+            for (int u = 0; u < KS; ++u) {
+                const int s = KS * nu + u;
+                if (s + 1 < STEPS)
+                    aq[(s + 1) & 1] = *reinterpret_cast<const f32x4*>(af + ((s + 1) / KS) * K::TILES * LDT + 8 * ((s + 1) % KS));
                 const f32x4 b = bq[s % BPF];
-                if (s + BPF < 64)
+                if (s + BPF < STEPS)
                     bq[s % BPF] = *reinterpret_cast<const f32x4*>(ux + WB(s + BPF));
-                if (xi == 3 && s == 64 - BPF) {                        // main phase has no more loads to issue
+                if (xi == 3 && s == STEPS - BPF) {                     // main phase has no more loads to issue
                     tail_prefetch(p.w3);
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) res[i] = *reinterpret_cast<const f32x4*>(xrow + (int64_t)(8 * i) * CC);
+                    for (int i = 0; i < 16; ++i) res[i] = *reinterpret_cast<const f32x4*>(xrow + (int64_t)(RP * i) * C);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -202,8 +227,9 @@ void wino_trunk_kernel(const WinoK p) {
             // pin the fold here: left to itself the compiler defers these adds to the end of the kernel and spills
             // every (xi, nu) accumulator to scratch meanwhile
             asm volatile("" : "+v"(y00), "+v"(y01), "+v"(y10), "+v"(y11));
-            if (nu < 3) STAMP(15 + 4 * xi + nu);                      // after nu = 0, 1, 2
+            if (nu < 3) STAMP(15 + 4 * xi + nu);
         }
+#undef WB
         // Next pass's input rows are requested only now.  Requesting them under this pass's MFMAs measured SLOWER
         // (0.499 vs 0.478 ms per launch), as did a longer weight-fragment prefetch: more loads in flight per CU back
         // up the vector-memory queue and the in-order wave stalls at issue, MFMAs included.  The partner workgroup of
@@ -213,13 +239,14 @@ void wino_trunk_kernel(const WinoK p) {
     }
 
     // ---- t2 = ELU(conv2 + b3a) + b3b -> T[pixel][channel].  The MFMAs ran with the weights as the row operand, so a
-    // lane holds tile (lane & 31) and, per register group g = r >> 2, four consecutive channels 8g + 4*hh + (r & 3):
-    // every LDS write below is 128 bits.
+    // lane holds tile (mt * 32 + lane & 31) and, per register group g = r >> 2, four consecutive channels
+    // 32 ns + 8g + 4*hh + (r & 3): every LDS write below is 128 bits.
     __syncthreads();                                                  // every wave is done with V of pass 3
     float* const T = lds;
     {
-        const int px = (2 * (li >> 4)) * 32 + 2 * (li & 15);          // top-left pixel of this lane's 2x2 output tile
-        float* const d = T + px * LDT + 32 * wave + 4 * hh;
+        const int tile = mt * 32 + li;
+        const int px = (2 * (tile / TC)) * W + 2 * (tile % TC);       // top-left pixel of this lane's 2x2 output tile
+        float* const d = T + px * LDT + 32 * ns + 4 * hh;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             f32x4 o00, o01, o10, o11;
@@ -232,15 +259,15 @@ void wino_trunk_kernel(const WinoK p) {
             }
             *reinterpret_cast<f32x4*>(d + 8 * g) = o00;
             *reinterpret_cast<f32x4*>(d + 8 * g + LDT) = o01;
-            *reinterpret_cast<f32x4*>(d + 8 * g + 32 * LDT) = o10;
-            *reinterpret_cast<f32x4*>(d + 8 * g + 33 * LDT) = o11;
+            *reinterpret_cast<f32x4*>(d + 8 * g + W * LDT) = o10;
+            *reinterpret_cast<f32x4*>(d + 8 * g + (W + 1) * LDT) = o11;
         }
     }
     STAMP(5);
     __syncthreads();
     STAMP(6);
 
-    // ---- tails: 2 x 2 waves over the 128 px x 128 ch tile, weight fragments straight from L2, D[channel][pixel] ------
+    // ---- tails: 64 px x 64 ch per wave over the PX x C tile, weight fragments straight from L2, D[channel][pixel] ------
     f32x16 acc[2][2];
     auto gemm_tail = [&](const float* __restrict__ wsrc) {
 #pragma unroll
@@ -250,15 +277,15 @@ void wino_trunk_kernel(const WinoK p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
         const float* a0 = T + (wm * 64 + li) * LDT + 4 * hh;
-        const float* b0 = wsrc + (wn * 2) * (16 * 256) + 4 * lane;
+        const float* b0 = wsrc + (wn * 2) * (KS * 256) + 4 * lane;
 #pragma unroll
-        for (int ug = 0; ug < 4; ++ug) {                              // bt[0] = first 4 k-slices: tail_prefetch()
-            if (ug + 1 < 4) {
+        for (int ug = 0; ug < KS / 4; ++ug) {                         // bt[0] = first 4 k-slices: tail_prefetch()
+            if (ug + 1 < KS / 4) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni)
-                        bt[(ug + 1) & 1][u][ni] = *reinterpret_cast<const f32x4*>(b0 + ni * (16 * 256) + 256 * (4 * (ug + 1) + u));
+                        bt[(ug + 1) & 1][u][ni] = *reinterpret_cast<const f32x4*>(b0 + ni * (KS * 256) + 256 * (4 * (ug + 1) + u));
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -288,7 +315,7 @@ void wino_trunk_kernel(const WinoK p) {
                     *reinterpret_cast<f32x4*>(T + (wm * 64 + mi * 32 + li) * LDT + wn * 64 + ni * 32 + 8 * g + 4 * hh) = o;
                 }
     };
-    float* const trow = T + tj0 * LDT + 4 * cg;                       // row-coalesced view: + (8 i) rows
+    float* const trow = T + tj0 * LDT + 4 * cg;                       // row-coalesced view: + (RP i) rows
 
     gemm_tail(p.w3);                                                  // conv3
     STAMP(7);
@@ -297,18 +324,18 @@ void wino_trunk_kernel(const WinoK p) {
     acc_to_lds();
     __syncthreads();
     STAMP(8);
-    // out = conv3 * scale + bias4 + x, in place over the residual stream, whole 512-byte rows per half wave
+    // out = conv3 * scale + bias4 + x, in place over the residual stream, whole pixel rows per RP-th of a workgroup
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        f32x4 t = *reinterpret_cast<const f32x4*>(trow + 8 * i * LDT);
+        f32x4 t = *reinterpret_cast<const f32x4*>(trow + RP * i * LDT);
         t = t * p.t_scale;
         t = t + p.t_b4;
         t = t + res[i];
-        *reinterpret_cast<f32x4*>(xrow + (int64_t)(8 * i) * CC) = t;
+        *reinterpret_cast<f32x4*>(xrow + (int64_t)(RP * i) * C) = t;
         if (TAIL == 2) {                                              // next block's conv1 pre-op, back into T in place
 #pragma unroll
             for (int e = 0; e < 4; ++e) t[e] = elu_act(t[e] + p.n_b1a) + p.n_b1b;
-            *reinterpret_cast<f32x4*>(trow + 8 * i * LDT) = t;
+            *reinterpret_cast<f32x4*>(trow + RP * i * LDT) = t;
         }
     }
     STAMP(9);
@@ -321,28 +348,22 @@ void wino_trunk_kernel(const WinoK p) {
         acc_to_lds();
         __syncthreads();
         STAMP(12);
-        float* const yrow = p.y2 + ((int64_t)m0 + tj0) * CC + 4 * cg;
+        float* const yrow = p.y2 + ((int64_t)m0 + tj0) * C + 4 * cg;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            f32x4 t = *reinterpret_cast<const f32x4*>(trow + 8 * i * LDT);
+            f32x4 t = *reinterpret_cast<const f32x4*>(trow + RP * i * LDT);
 #pragma unroll
             for (int e = 0; e < 4; ++e) t[e] = elu_act(t[e] + p.n_b2a) + p.n_b2b;
-            *reinterpret_cast<f32x4*>(yrow + (int64_t)(8 * i) * CC) = t;
+            *reinterpret_cast<f32x4*>(yrow + (int64_t)(RP * i) * C) = t;
         }
         STAMP(13);
     }
 }
 
-// Fragment order of a [128 n][128 k] matrix: element (n, k) of the 32-row tile n >> 5 and 8-wide k-slice k >> 3 goes to
-// lane (k >> 2 & 1) * 32 + (n & 31), component k & 3 -- what lane (li = n & 31, hh) feeds to MFMA number k & 3 of the slice.
-__device__ __forceinline__ int frag_offset(int n, int k) {
-    return (((n >> 5) * 16 + (k >> 3)) * 64 + ((k >> 2) & 1) * 32 + (n & 31)) * 4 + (k & 3);
-}
-
 // U[xi*4 + nu] = (G g G^T)[xi][nu] for g = w[n][k][3][3];  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
-__global__ void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;              // over n * 128 + k
-    if (i >= CC * CC) return;
+__global__ void wino_weight_kernel(const float* __restrict__ w, int c, float* __restrict__ U) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;              // over n * c + k
+    if (i >= c * c) return;
     float g[3][3], t[4][3];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -355,92 +376,103 @@ __global__ void wino_weight_kernel(const float* __restrict__ w, float* __restric
         t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
         t[3][b] = g[2][b];
     }
-    const int fo = frag_offset(i / CC, i % CC);
+    const int fo = frag_offset(i / c, i % c, c);
+    const int64_t cc = (int64_t)c * c;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-        U[(int64_t)(a * 4 + 0) * CC * CC + fo] = t[a][0];
-        U[(int64_t)(a * 4 + 1) * CC * CC + fo] = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
-        U[(int64_t)(a * 4 + 2) * CC * CC + fo] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
-        U[(int64_t)(a * 4 + 3) * CC * CC + fo] = t[a][2];
+        U[(a * 4 + 0) * cc + fo] = t[a][0];
+        U[(a * 4 + 1) * cc + fo] = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
+        U[(a * 4 + 2) * cc + fo] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
+        U[(a * 4 + 3) * cc + fo] = t[a][2];
     }
 }
 
-// packed [128 n][128 k] (vqae_conv_pack_weight_f32) -> fragment order
-__global__ void frag_weight_kernel(const float* __restrict__ w, float* __restrict__ out) {
+// packed [c n][c k] (vqae_conv_pack_weight_f32) -> fragment order
+__global__ void frag_weight_kernel(const float* __restrict__ w, int c, float* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= CC * CC) return;
-    out[frag_offset(i / CC, i % CC)] = w[i];
+    if (i >= c * c) return;
+    out[frag_offset(i / c, i % c, c)] = w[i];
+}
+
+template <int C>
+int launch_wino(const WinoK& k, bool chain, hipStream_t stream) {
+    using K = WinoCfg<C>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)wino_trunk_kernel<C, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES));
+        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)wino_trunk_kernel<C, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES));
+        attr_set = true;
+    }
+    const unsigned grid = (unsigned)(k.M / K::PX);
+    // executed matrix work: 16 GEMMs of K = C per 4 output pixels (K_eff = 4 C per pixel) + the 1x1 tails
+    const double flops = 2.0 * (double)k.M * C * (4.0 * C + C + (chain ? C : 0));
+    vqae::ProfScope prof(C == 128 ? vqae::PROF_CONV3X3_TRUNK : vqae::PROF_NONE, stream, flops);
+    if (chain) wino_trunk_kernel<C, 2><<<grid, 256, K::LDS_BYTES, stream>>>(k);
+    else wino_trunk_kernel<C, 1><<<grid, 256, K::LDS_BYTES, stream>>>(k);
+    prof.done();
+    VQAE_LAUNCH_CHECK();
+    return VQAE_OK;
 }
 
 }  // namespace
 
 namespace vqae {
 
-bool wino_trunk_supported(int c, int h, int w) { return c == CC && w == 32 && h >= 4 && h % 4 == 0; }
+bool wino_trunk_supported(int c, int h, int w) {
+    return ((c == 128 && w == 32) || (c == 64 && w == 64)) && h >= 4 && h % 4 == 0;
+}
 
-size_t wino_weight_floats() { return (size_t)16 * CC * CC; }
+size_t wino_weight_floats(int c) { return (size_t)16 * c * c; }
 
-// w_oihw_dev [128][128][3][3] (PyTorch layout, device) -> U_dev [16][128][128]
-int wino_transform_weight(const float* w_oihw_dev, float* U_dev, hipStream_t stream) {
-    wino_weight_kernel<<<CC * CC / 256, 256, 0, stream>>>(w_oihw_dev, U_dev);
+// w_oihw_dev [c][c][3][3] (PyTorch layout, device) -> U_dev [16][c][c] (fragment order)
+int wino_transform_weight(const float* w_oihw_dev, int c, float* U_dev, hipStream_t stream) {
+    wino_weight_kernel<<<(unsigned)ceil_div(c * c, 256), 256, 0, stream>>>(w_oihw_dev, c, U_dev);
     VQAE_LAUNCH_CHECK();
     return VQAE_OK;
 }
 
-// packed [128][128] 1x1 weights (device) -> fragment order (device)
-int wino_frag_weight(const float* w_packed_dev, float* out_dev, hipStream_t stream) {
-    frag_weight_kernel<<<CC * CC / 256, 256, 0, stream>>>(w_packed_dev, out_dev);
+// packed [c][c] 1x1 weights (device) -> fragment order (device)
+int wino_frag_weight(const float* w_packed_dev, int c, float* out_dev, hipStream_t stream) {
+    frag_weight_kernel<<<(unsigned)ceil_div(c * c, 256), 256, 0, stream>>>(w_packed_dev, c, out_dev);
     VQAE_LAUNCH_CHECK();
     return VQAE_OK;
 }
 
-// Same contract as conv_trunk_tail (conv_mfma.hip) for C = 128, W = 32, fp32: t1 -> xio in place (+ t1_next).
+// Same contract as conv_trunk_tail (conv_mfma.hip), fp32, (C, W) in {(128, 32), (64, 64)}: t1 -> xio in place (+ t1_next).
+// U, w3, w1n in fragment order.
 int wino_trunk_tail(const float* t1, const float* U, const float* w3, float act_a, float act_b, float t_scale, float t_b4,
                     float* xio, const float* w1n, float n_b1a, float n_b1b, float n_b2a, float n_b2b, float* t1_next,
-                    int batch, int h, hipStream_t stream) {
+                    int batch, int h, int w, int c, hipStream_t stream) {
     if (batch == 0) return VQAE_OK;
     VQAE_REQUIRE(t1 && U && w3 && xio && (!w1n || t1_next), VQAE_ERR_INVALID, "wino_trunk_tail: null pointer");
-    VQAE_REQUIRE(wino_trunk_supported(CC, h, 32), VQAE_ERR_UNSUPPORTED, "wino_trunk_tail: H = %d", h);
-    const int64_t M = (int64_t)batch * h * 32;
+    VQAE_REQUIRE(wino_trunk_supported(c, h, w), VQAE_ERR_UNSUPPORTED, "wino_trunk_tail: C = %d, H = %d, W = %d", c, h, w);
+    const int64_t M = (int64_t)batch * h * w;
     VQAE_REQUIRE(M < (1ll << 31) - 256, VQAE_ERR_UNSUPPORTED, "wino_trunk_tail: too many pixels");
     WinoK k;
+    memset(&k, 0, sizeof(k));
     k.t1 = t1; k.U = U; k.w3 = w3; k.w1n = w1n; k.xio = xio; k.y2 = t1_next;
     k.H = h; k.M = (int)M;
     k.act_a = act_a; k.act_b = act_b; k.t_scale = t_scale; k.t_b4 = t_b4;
     k.n_b1a = n_b1a; k.n_b1b = n_b1b; k.n_b2a = n_b2a; k.n_b2b = n_b2b;
-    constexpr int lds_bytes = 128 * LDT * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)wino_trunk_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)wino_trunk_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        attr_set = true;
-    }
-    const unsigned grid = (unsigned)(M / 128);
-    // executed matrix work: 16 GEMMs of K = 128 per 4 output pixels (K_eff = 512 per pixel) + the 1x1 tails
-    const double flops = 2.0 * (double)M * CC * (4.0 * CC + CC + (w1n ? CC : 0));
-    ProfScope prof(PROF_CONV3X3_TRUNK, stream, flops);
 #ifdef VQAE_WINO_TRACE
     static unsigned long long* trace = nullptr;
-    static int launches = 0;
     if (!trace) (void)hipMalloc((void**)&trace, (size_t)4096 * 128 * 8);
-    VQAE_REQUIRE(trace && grid <= 4096, VQAE_ERR_UNSUPPORTED, "trace build: grid %u > 4096", grid);
+    VQAE_REQUIRE(trace && M / 128 <= 4096, VQAE_ERR_UNSUPPORTED, "trace build: too many workgroups");
     k.trace = trace;
 #endif
-    if (w1n) wino_trunk_kernel<2><<<grid, 256, lds_bytes, stream>>>(k);
-    else wino_trunk_kernel<1><<<grid, 256, lds_bytes, stream>>>(k);
-    prof.done();
+    const int rc = c == 128 ? launch_wino<128>(k, w1n != nullptr, stream) : launch_wino<64>(k, w1n != nullptr, stream);
 #ifdef VQAE_WINO_TRACE
-    if (w1n && grid == 2048 && ++launches == 200) {       // one steady-state launch of the B = 256 bench
+    static int launches = 0;
+    if (rc == VQAE_OK && c == 128 && w1n && M / 128 == 2048 && ++launches == 200) {   // one steady-state launch of the B = 256 bench
         (void)hipStreamSynchronize(stream);
-        unsigned long long* host = new unsigned long long[(size_t)grid * 128];
-        (void)hipMemcpy(host, trace, (size_t)grid * 128 * 8, hipMemcpyDeviceToHost);
+        unsigned long long* host = new unsigned long long[(size_t)2048 * 128];
+        (void)hipMemcpy(host, trace, (size_t)2048 * 128 * 8, hipMemcpyDeviceToHost);
         FILE* f = fopen("gpurun_out/wino_trace.bin", "wb");
-        if (f) { fwrite(host, 8, (size_t)grid * 128, f); fclose(f); }
+        if (f) { fwrite(host, 8, (size_t)2048 * 128, f); fclose(f); }
         delete[] host;
     }
 #endif
-    VQAE_LAUNCH_CHECK();
-    return VQAE_OK;
+    return rc;
 }
 
 }  // namespace vqae

@@ -22,12 +22,12 @@ int conv_trunk_tail(const vqae_conv_args* a, const float* t1, const float* w2, c
                     float t_b4, float* xio, const float* w1n, float n_b1a, float n_b1b, float n_b2a, float n_b2b,
                     float* t1_next, hipStream_t stream);
 bool wino_trunk_supported(int c, int h, int w);
-size_t wino_weight_floats();
-int wino_transform_weight(const float* w_oihw_dev, float* U_dev, hipStream_t stream);
-int wino_frag_weight(const float* w_packed_dev, float* out_dev, hipStream_t stream);
+size_t wino_weight_floats(int c);
+int wino_transform_weight(const float* w_oihw_dev, int c, float* U_dev, hipStream_t stream);
+int wino_frag_weight(const float* w_packed_dev, int c, float* out_dev, hipStream_t stream);
 int wino_trunk_tail(const float* t1, const float* U, const float* w3, float act_a, float act_b, float t_scale, float t_b4,
                     float* xio, const float* w1n, float n_b1a, float n_b1b, float n_b2a, float n_b2b, float* t1_next,
-                    int batch, int h, hipStream_t stream);
+                    int batch, int h, int w, int c, hipStream_t stream);
 int conv3x3_direct(const void* x, int x_kind, const float* mean255, const float* inv_std255, const float* w,
                    const float* bias, int B, int H, int W, int cin, int cout, float* y, int y_nchw, int dt,
                    hipStream_t stream);
@@ -87,7 +87,7 @@ struct Block {
     int mode, cin, cout, br;
     float b1a, b1b, b2a, b2b, b3a, b3b, b4, scale, b1c, b1d;
     float *w1, *w2, *w3, *wskip;          // packed, device
-    float* wU = nullptr;                  // Winograd-domain conv2 weights [16][128][128] (fp32 trunk blocks, conv_wino.hip)
+    float* wU = nullptr;                  // Winograd-domain conv2 weights [16][C][C] (fp32 trunk blocks, C = 64 / 128, conv_wino.hip)
     float *w1f = nullptr, *w3f = nullptr; // conv1 / conv3 weights in MFMA fragment order for that kernel's tails
     // MBConv (conv_block.py:240-321), BatchNorms folded: br = expanded width, w2 = depthwise taps [k*k][br]
     int kind = VQAE_BLOCK_FIXUP, hidden = 0;
@@ -119,7 +119,7 @@ struct vqae_handle {
     bool fuse_trunk = true;                // conv2 + conv3 (+ next conv1) in one launch at the 128-channel trunk
     bool t1_ready = false;                 // buf[1] already holds the current block's t1
     bool up_conv_first = true;             // fp32 up blocks: 1x1 convs before the bicubic resize (they commute)
-    bool use_wino = true;                  // fp32 trunk blocks (C = 128, 32-wide grid): Winograd F(2x2,3x3) conv2
+    bool use_wino = true;                  // fp32 trunk blocks (C = 128 on a 32-wide grid, C = 64 on a 64-wide one): Winograd F(2x2,3x3) conv2
     void* idx_scratch = nullptr;           // indices nobody asked for (vqae_forward with idx == NULL)
     size_t idx_scratch_bytes = 0;
     float* se_ws = nullptr;                // MBConv: SE partial sums, then the gate [B][E]
@@ -177,16 +177,16 @@ int upload_packed(vqae_handle* h, const float* host, int cout, int cin, int ks, 
     return rc;
 }
 
-// conv2 weights [128][128][3][3] (host, PyTorch layout) -> Winograd domain on the device
-int upload_wino(vqae_handle* h, const float* host, float** out) {
+// conv2 weights [c][c][3][3] (host, PyTorch layout) -> Winograd domain on the device
+int upload_wino(vqae_handle* h, const float* host, int c, float** out) {
     void* tmp = nullptr;
-    const size_t raw = (size_t)128 * 128 * 9 * 4;
+    const size_t raw = (size_t)c * c * 9 * 4;
     if (hipMalloc(&tmp, raw) != hipSuccess) return vqae::fail(VQAE_ERR_NOMEM, "hipMalloc failed");
     hipError_t e = hipMemcpy(tmp, host, raw, hipMemcpyHostToDevice);
     void* U = nullptr;
-    int rc = (e == hipSuccess) ? dev_alloc(h, vqae::wino_weight_floats() * 4, &U)
+    int rc = (e == hipSuccess) ? dev_alloc(h, vqae::wino_weight_floats(c) * 4, &U)
                                : vqae::fail(VQAE_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(e));
-    if (rc == VQAE_OK) rc = vqae::wino_transform_weight((const float*)tmp, (float*)U, nullptr);
+    if (rc == VQAE_OK) rc = vqae::wino_transform_weight((const float*)tmp, c, (float*)U, nullptr);
     if (rc == VQAE_OK && hipDeviceSynchronize() != hipSuccess) rc = vqae::fail(VQAE_ERR_HIP, "winograd weight transform failed");
     (void)hipFree(tmp);
     *out = (float*)U;
@@ -216,15 +216,15 @@ int load_block(vqae_handle* h, const TensorMap& tm, const std::string& pre, int 
     if ((rc = find(tm, pre + ".branch_conv2.weight", (int64_t)b->br * b->br * k2 * k2, &p))) return rc;
     if ((rc = upload_packed(h, p, b->br, b->br, k2, &b->w2))) return rc;
     b->wU = b->w1f = b->w3f = nullptr;
-    const bool wino = mode == MODE_SAME && cin == 128 && cout == 128 && h->cfg.compute_dtype == VQAE_DT_F32 && h->use_wino;
-    if (wino && (rc = upload_wino(h, p, &b->wU))) return rc;
+    const bool wino = mode == MODE_SAME && (cin == 128 || cin == 64) && cout == cin && h->cfg.compute_dtype == VQAE_DT_F32 && h->use_wino;
+    if (wino && (rc = upload_wino(h, p, cin, &b->wU))) return rc;
     if ((rc = find(tm, pre + ".branch_conv3.weight", (int64_t)cout * b->br, &p))) return rc;
     if ((rc = upload_packed(h, p, cout, b->br, 1, &b->w3))) return rc;
     if (wino) {
         void *f1, *f3;
-        if ((rc = dev_alloc(h, 128 * 128 * 4, &f1)) || (rc = dev_alloc(h, 128 * 128 * 4, &f3))) return rc;
+        if ((rc = dev_alloc(h, (size_t)cin * cin * 4, &f1)) || (rc = dev_alloc(h, (size_t)cin * cin * 4, &f3))) return rc;
         b->w1f = (float*)f1; b->w3f = (float*)f3;
-        if ((rc = vqae::wino_frag_weight(b->w1, b->w1f, nullptr)) || (rc = vqae::wino_frag_weight(b->w3, b->w3f, nullptr))) return rc;
+        if ((rc = vqae::wino_frag_weight(b->w1, cin, b->w1f, nullptr)) || (rc = vqae::wino_frag_weight(b->w3, cin, b->w3f, nullptr))) return rc;
         VQAE_HIP_CHECK(hipDeviceSynchronize());
     }
     if (mode != MODE_SAME) {
@@ -384,7 +384,7 @@ int run_block(vqae_handle* h, const Block& b, const Block* next, int B, int& H, 
         if (b.wU && g_dt == VQAE_DT_F32 && vqae::wino_trunk_supported(b.cin, H, W) && (!chain || next->w1f)) {
             if ((rc = vqae::wino_trunk_tail(P, b.wU, b.w3f, b.b3a, b.b3b, b.scale, b.b4, X, chain ? next->w1f : nullptr,
                                             chain ? next->b1a : 0.f, chain ? next->b1b : 0.f, chain ? next->b2a : 0.f,
-                                            chain ? next->b2b : 0.f, chain ? Q : nullptr, B, H, st))) return rc;
+                                            chain ? next->b2b : 0.f, chain ? Q : nullptr, B, H, W, b.cin, st))) return rc;
             if (chain) std::swap(h->buf[1], h->buf[2]);
             h->t1_ready = chain;
             return VQAE_OK;

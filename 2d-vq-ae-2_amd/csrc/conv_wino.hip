@@ -56,7 +56,7 @@ struct WinoK {
 constexpr int BPF = 6;                   // weight-fragment prefetch distance (k-slices)
 
 template <int C> struct WinoCfg {
-    static constexpr int W = C == 128 ? 32 : 64;      // grid width this channel count runs at
+    static constexpr int W = C == 128 ? 32 : (C == 64 ? 64 : 128);   // grid width this channel count runs at
     static constexpr int PX = 4 * W;                   // output pixels per workgroup (4 image rows)
     static constexpr int TILES = PX / 4;               // 2x2 output tiles per workgroup
     static constexpr int TC = W / 2;                   // tile columns
@@ -65,7 +65,9 @@ template <int C> struct WinoCfg {
     static constexpr int C4 = C / 4;                   // float4 per pixel
     static constexpr int RP = 256 / C4;                // pixels (or tile columns) covered by one sweep of the 256 threads
     static constexpr int LDT = C + 4;                  // LDS row stride (floats): conflict-free ds_read_b128 fragments
-    static constexpr int WN = C / 64;                  // tails: waves along the channels (64 each), 4 / WN along the pixels
+    static constexpr int NI = C >= 64 ? 2 : 1;         // tails: 32-channel tiles per wave
+    static constexpr int WN = C / (32 * NI);           //        waves along the channels, 4 / WN along the pixels
+    static constexpr int MI = PX / ((4 / WN) * 32);    //        32-pixel tiles per wave (MI * NI = 4 accumulators)
     static constexpr int LDS_BYTES = PX * LDT * 4;     // V[4][TILES][LDT] and T[PX][LDT] overlay each other
 };
 
@@ -80,6 +82,7 @@ __global__ __launch_bounds__(256, 2)
 void wino_trunk_kernel(const WinoK p) {
     using K = WinoCfg<C>;
     constexpr int W = K::W, PX = K::PX, TC = K::TC, NS = K::NS, KS = K::KS, C4 = K::C4, RP = K::RP, LDT = K::LDT, WN = K::WN;
+    constexpr int MI = K::MI, NI = K::NI;
     constexpr int STEPS = 4 * KS;                                    // k-slices per pass (4 nu)
     extern __shared__ __attribute__((aligned(16))) float lds[];      // V[4][TILES][LDT]  /  T[PX][LDT]
     const int tid = threadIdx.x;
@@ -152,16 +155,16 @@ void wino_trunk_kernel(const WinoK p) {
     // Tail operands requested while the last pass's MFMAs run.  vmcnt retires in order (stores included), so a load
     // issued behind a slow one waits for it: the residual rows (HBM) go out after the last weight-fragment load of
     // the main phase, the first weight fragments of each tail GEMM before the stores of the epilogue in front of it.
-    const int wm = wave / WN, wn = wave % WN;                        // tails: 64 pixels x 64 channels per wave
+    const int wm = wave / WN, wn = wave % WN;                        // tails: MI*32 pixels x NI*32 channels per wave
     float* const xrow = p.xio + ((int64_t)m0 + tj0) * C + 4 * cg;    // row-coalesced view of the tile: + RP * i rows
     f32x4 res[16];
-    f32x4 bt[2][4][2];
+    f32x4 bt[2][4][NI];
     auto tail_prefetch = [&](const float* __restrict__ wsrc) {
-        const float* b0 = wsrc + (wn * 2) * (KS * 256) + 4 * lane;
+        const float* b0 = wsrc + (wn * NI) * (KS * 256) + 4 * lane;
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) bt[0][u][ni] = *reinterpret_cast<const f32x4*>(b0 + ni * (KS * 256) + 256 * u);
+            for (int ni = 0; ni < NI; ++ni) bt[0][u][ni] = *reinterpret_cast<const f32x4*>(b0 + ni * (KS * 256) + 256 * u);
     };
 
     STAMP(0);
@@ -268,51 +271,51 @@ void wino_trunk_kernel(const WinoK p) {
     STAMP(6);
 
     // ---- tails: 64 px x 64 ch per wave over the PX x C tile, weight fragments straight from L2, D[channel][pixel] ------
-    f32x16 acc[2][2];
+    f32x16 acc[MI][NI];
     auto gemm_tail = [&](const float* __restrict__ wsrc) {
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+            for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-        const float* a0 = T + (wm * 64 + li) * LDT + 4 * hh;
-        const float* b0 = wsrc + (wn * 2) * (KS * 256) + 4 * lane;
+        const float* a0 = T + (wm * MI * 32 + li) * LDT + 4 * hh;
+        const float* b0 = wsrc + (wn * NI) * (KS * 256) + 4 * lane;
 #pragma unroll
         for (int ug = 0; ug < KS / 4; ++ug) {                         // bt[0] = first 4 k-slices: tail_prefetch()
             if (ug + 1 < KS / 4) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
+                    for (int ni = 0; ni < NI; ++ni)
                         bt[(ug + 1) & 1][u][ni] = *reinterpret_cast<const f32x4*>(b0 + ni * (KS * 256) + 256 * (4 * (ug + 1) + u));
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                f32x4 a[2];
+                f32x4 a[MI];
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(a0 + mi * 32 * LDT + 8 * (4 * ug + u));
+                for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(a0 + mi * 32 * LDT + 8 * (4 * ug + u));
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int mi = 0; mi < 2; ++mi)
+                    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                        for (int ni = 0; ni < 2; ++ni)
+                        for (int ni = 0; ni < NI; ++ni)
                             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(bt[ug & 1][u][ni][r], a[mi][r], acc[mi][ni], 0, 0, 0);
             }
         }
     };
     auto acc_to_lds = [&]() {                                         // D[channel][pixel] -> T[pixel][channel], 128-bit writes
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = acc[mi][ni][4 * g + e];
-                    *reinterpret_cast<f32x4*>(T + (wm * 64 + mi * 32 + li) * LDT + wn * 64 + ni * 32 + 8 * g + 4 * hh) = o;
+                    *reinterpret_cast<f32x4*>(T + (wm * MI * 32 + mi * 32 + li) * LDT + (wn * NI + ni) * 32 + 8 * g + 4 * hh) = o;
                 }
     };
     float* const trow = T + tj0 * LDT + 4 * cg;                       // row-coalesced view: + (RP i) rows
@@ -419,7 +422,7 @@ int launch_wino(const WinoK& k, bool chain, hipStream_t stream) {
 namespace vqae {
 
 bool wino_trunk_supported(int c, int h, int w) {
-    return ((c == 128 && w == 32) || (c == 64 && w == 64)) && h >= 4 && h % 4 == 0;
+    return ((c == 128 && w == 32) || (c == 64 && w == 64) || (c == 32 && w == 128)) && h >= 4 && h % 4 == 0;
 }
 
 size_t wino_weight_floats(int c) { return (size_t)16 * c * c; }
@@ -438,7 +441,7 @@ int wino_frag_weight(const float* w_packed_dev, int c, float* out_dev, hipStream
     return VQAE_OK;
 }
 
-// Same contract as conv_trunk_tail (conv_mfma.hip), fp32, (C, W) in {(128, 32), (64, 64)}: t1 -> xio in place (+ t1_next).
+// Same contract as conv_trunk_tail (conv_mfma.hip), fp32, (C, W) in {(128, 32), (64, 64), (32, 128)}: t1 -> xio in place (+ t1_next).
 // U, w3, w1n in fragment order.
 int wino_trunk_tail(const float* t1, const float* U, const float* w3, float act_a, float act_b, float t_scale, float t_b4,
                     float* xio, const float* w1n, float n_b1a, float n_b1b, float n_b2a, float n_b2b, float* t1_next,
@@ -460,7 +463,8 @@ int wino_trunk_tail(const float* t1, const float* U, const float* w3, float act_
     VQAE_REQUIRE(trace && M / 128 <= 4096, VQAE_ERR_UNSUPPORTED, "trace build: too many workgroups");
     k.trace = trace;
 #endif
-    const int rc = c == 128 ? launch_wino<128>(k, w1n != nullptr, stream) : launch_wino<64>(k, w1n != nullptr, stream);
+    const int rc = c == 128 ? launch_wino<128>(k, w1n != nullptr, stream)
+                 : (c == 64 ? launch_wino<64>(k, w1n != nullptr, stream) : launch_wino<32>(k, w1n != nullptr, stream));
 #ifdef VQAE_WINO_TRACE
     static int launches = 0;
     if (rc == VQAE_OK && c == 128 && w1n && M / 128 == 2048 && ++launches == 200) {   // one steady-state launch of the B = 256 bench

@@ -216,7 +216,8 @@ int load_block(vqae_handle* h, const TensorMap& tm, const std::string& pre, int 
     if ((rc = find(tm, pre + ".branch_conv2.weight", (int64_t)b->br * b->br * k2 * k2, &p))) return rc;
     if ((rc = upload_packed(h, p, b->br, b->br, k2, &b->w2))) return rc;
     b->wU = b->w1f = b->w3f = nullptr;
-    const bool wino = mode == MODE_SAME && (cin == 128 || cin == 64) && cout == cin && h->cfg.compute_dtype == VQAE_DT_F32 && h->use_wino;
+    const bool wino = mode == MODE_SAME && (cin == 128 || cin == 64 || cin == 32) && cout == cin &&
+                      h->cfg.compute_dtype == VQAE_DT_F32 && h->use_wino;
     if (wino && (rc = upload_wino(h, p, cin, &b->wU))) return rc;
     if ((rc = find(tm, pre + ".branch_conv3.weight", (int64_t)cout * b->br, &p))) return rc;
     if ((rc = upload_packed(h, p, cout, b->br, 1, &b->w3))) return rc;
@@ -372,16 +373,17 @@ int run_block(vqae_handle* h, const Block& b, const Block* next, int B, int& H, 
     if (b.kind == VQAE_BLOCK_MBCONV) return run_mbconv(h, b, B, H, W, st);
     float *X = h->buf[0], *P = h->buf[1], *Q = h->buf[2], *R = h->buf[3];
     int rc;
-    if (b.mode == MODE_SAME && (b.cin == 128 || b.cin == 64) && b.cout == b.cin && h->fuse_trunk) {
+    const bool wino = b.mode == MODE_SAME && b.wU && g_dt == VQAE_DT_F32 && h->fuse_trunk && vqae::wino_trunk_supported(b.cin, H, W);
+    if (b.mode == MODE_SAME && (wino || ((b.cin == 128 || b.cin == 64) && b.cout == b.cin && h->fuse_trunk))) {
         // trunk: conv1 (unless the previous block's tail already produced t1 in P), then ONE launch for
-        // conv2 + conv3 (+ the next block's conv1 when it is another 128-channel 'same' block)
+        // conv2 + conv3 (+ the next block's conv1 when it is another 'same' block of this width)
         if (!h->t1_ready) {
             ConvCall c1(B, H, W, b.cin, b.br, 1, 1, 0, VQAE_PAD_NONE);
             c1.pre(VQAE_PRE_BIAS_ELU_BIAS, b.b1a, b.b1b).act(b.b2a, b.b2b);
             if ((rc = vqae_conv2d_f32(&c1.a, X, b.w1, nullptr, nullptr, P, st))) return rc;
         }
-        const bool chain = next && next->mode == MODE_SAME && next->cin == b.cin && next->cout == b.cin;
-        if (b.wU && g_dt == VQAE_DT_F32 && vqae::wino_trunk_supported(b.cin, H, W) && (!chain || next->w1f)) {
+        const bool chain = next && next->mode == MODE_SAME && next->cin == b.cin && next->cout == b.cin && (!wino || next->w1f);
+        if (wino) {
             if ((rc = vqae::wino_trunk_tail(P, b.wU, b.w3f, b.b3a, b.b3b, b.scale, b.b4, X, chain ? next->w1f : nullptr,
                                             chain ? next->b1a : 0.f, chain ? next->b1b : 0.f, chain ? next->b2a : 0.f,
                                             chain ? next->b2b : 0.f, chain ? Q : nullptr, B, H, W, b.cin, st))) return rc;

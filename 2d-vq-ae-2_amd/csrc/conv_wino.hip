@@ -48,7 +48,7 @@ struct WinoK {
 // Developer aid (off by default): per-phase s_memtime stamps of every wave -> gpurun_out/wino_trace.bin.  It showed that
 // the cost of this kernel's first version sat in the L1 tag pipe (row-major weight fragments), not in HBM or the MFMAs.
 #ifdef VQAE_WINO_TRACE
-#define STAMP(i) do { if (lane == 0) p.trace[((int64_t)blockIdx.x * 4 + wave) * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP(i) do { if (lane == 0 && p.trace) p.trace[((int64_t)blockIdx.x * 4 + wave) * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMP(i) do {} while (0)
 #endif
@@ -460,8 +460,7 @@ int wino_trunk_tail(const float* t1, const float* U, const float* w3, float act_
 #ifdef VQAE_WINO_TRACE
     static unsigned long long* trace = nullptr;
     if (!trace) (void)hipMalloc((void**)&trace, (size_t)4096 * 128 * 8);
-    VQAE_REQUIRE(trace && M / 128 <= 4096, VQAE_ERR_UNSUPPORTED, "trace build: too many workgroups");
-    k.trace = trace;
+    k.trace = (c == 128 && M / 128 <= 4096) ? trace : nullptr;
 #endif
     const int rc = c == 128 ? launch_wino<128>(k, w1n != nullptr, stream)
                  : (c == 64 ? launch_wino<64>(k, w1n != nullptr, stream) : launch_wino<32>(k, w1n != nullptr, stream));

@@ -105,43 +105,68 @@ void conv3x3_direct_kernel(const void* __restrict__ xin, int x_kind, Norm3 nrm, 
 // i-2..i+1) or .25 (odd outputs, taps at i-1..i+2) with i = o >> 1; out = sum_i wy_i * (sum_j wx_j * v_ij),
 // both sums left to right, unfused (oracle: bicubic_up2_explicit).
 // ------------------------------------------------------------------------------------------------
+// One thread = one 2x2 output block (oy in {2i+1, 2i+2}, ox in {2j+1, 2j+2}): these four outputs read the same 4x4
+// input window (rows i-1..i+2, columns j-1..j+2), so it is loaded once -- 4 loads per output instead of 16.  Blocks
+// i = -1 and i = H-1 (j likewise) have one valid row (column).  Per-output arithmetic and its order are unchanged.
 __global__ __launch_bounds__(256)
 void bicubic_up2_kernel(const float4* __restrict__ x, int B, int H, int W, int C4, float pre_bias,
                         float4* __restrict__ y) {
-    const float w75[4] = {-0.03515625f, 0.26171875f, 0.87890625f, -0.10546875f};
-    const float w25[4] = {-0.10546875f, 0.87890625f, 0.26171875f, -0.03515625f};
-    const int OH = 2 * H, OW = 2 * W;
-    const int64_t total = (int64_t)B * OH * OW * C4;
+    const float w75[4] = {-0.03515625f, 0.26171875f, 0.87890625f, -0.10546875f};   // even outputs (offset .75)
+    const float w25[4] = {-0.10546875f, 0.87890625f, 0.26171875f, -0.03515625f};   // odd outputs  (offset .25)
+    const int OW = 2 * W, OH = 2 * H;
+    const int64_t total = (int64_t)B * (H + 1) * (W + 1) * C4;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int c4 = (int)(i % C4);
         int64_t p = i / C4;
-        const int ox = (int)(p % OW); p /= OW;
-        const int oy = (int)(p % OH);
-        const int b = (int)(p / OH);
-        const int by = (oy >> 1) - ((oy & 1) ? 1 : 2);
-        const int bx = (ox >> 1) - ((ox & 1) ? 1 : 2);
-        const float* wy = (oy & 1) ? w25 : w75;
-        const float* wx = (ox & 1) ? w25 : w75;
-        int xs[4];
+        const int bj = (int)(p % (W + 1)) - 1; p /= (W + 1);
+        const int bi = (int)(p % (H + 1)) - 1;
+        const int b = (int)(p / (H + 1));
+        int xs[4], ys[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { int v = bx + j; xs[j] = v < 0 ? 0 : (v > W - 1 ? W - 1 : v); }
-        float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < 4; ++j) {
+            int v = bj - 1 + j; xs[j] = v < 0 ? 0 : (v > W - 1 ? W - 1 : v);
+            int u = bi - 1 + j; ys[j] = u < 0 ? 0 : (u > H - 1 ? H - 1 : u);
+        }
+        float4 ho[4], he[4];                            // horizontally interpolated rows: odd / even output column
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            int yy = by + r; yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
-            const float4* row = x + ((int64_t)b * H + yy) * W * C4 + c4;
-            float4 in;
+            const float4* row = x + ((int64_t)b * H + ys[r]) * W * C4 + c4;
+            float4 v[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float4 v = row[(int64_t)xs[j] * C4];
-                v.x += pre_bias; v.y += pre_bias; v.z += pre_bias; v.w += pre_bias;
-                if (j == 0) { in.x = v.x * wx[0]; in.y = v.y * wx[0]; in.z = v.z * wx[0]; in.w = v.w * wx[0]; }
-                else { in.x = in.x + v.x * wx[j]; in.y = in.y + v.y * wx[j]; in.z = in.z + v.z * wx[j]; in.w = in.w + v.w * wx[j]; }
+                v[j] = row[(int64_t)xs[j] * C4];
+                v[j].x += pre_bias; v[j].y += pre_bias; v[j].z += pre_bias; v[j].w += pre_bias;
             }
-            if (r == 0) { out.x = in.x * wy[0]; out.y = in.y * wy[0]; out.z = in.z * wy[0]; out.w = in.w * wy[0]; }
-            else { out.x = out.x + in.x * wy[r]; out.y = out.y + in.y * wy[r]; out.z = out.z + in.z * wy[r]; out.w = out.w + in.w * wy[r]; }
+            ho[r].x = v[0].x * w25[0]; ho[r].y = v[0].y * w25[0]; ho[r].z = v[0].z * w25[0]; ho[r].w = v[0].w * w25[0];
+            he[r].x = v[0].x * w75[0]; he[r].y = v[0].y * w75[0]; he[r].z = v[0].z * w75[0]; he[r].w = v[0].w * w75[0];
+#pragma unroll
+            for (int j = 1; j < 4; ++j) {
+                ho[r].x = ho[r].x + v[j].x * w25[j]; ho[r].y = ho[r].y + v[j].y * w25[j];
+                ho[r].z = ho[r].z + v[j].z * w25[j]; ho[r].w = ho[r].w + v[j].w * w25[j];
+                he[r].x = he[r].x + v[j].x * w75[j]; he[r].y = he[r].y + v[j].y * w75[j];
+                he[r].z = he[r].z + v[j].z * w75[j]; he[r].w = he[r].w + v[j].w * w75[j];
+            }
         }
-        y[i] = out;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {                   // a = 0: odd output row 2 bi + 1, a = 1: even row 2 bi + 2
+            const int oy = 2 * bi + 1 + a;
+            if (oy < 0 || oy >= OH) continue;
+            const float* wy = a == 0 ? w25 : w75;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int ox = 2 * bj + 1 + c;
+                if (ox < 0 || ox >= OW) continue;
+                const float4* in = c == 0 ? ho : he;
+                float4 out;
+                out.x = in[0].x * wy[0]; out.y = in[0].y * wy[0]; out.z = in[0].z * wy[0]; out.w = in[0].w * wy[0];
+#pragma unroll
+                for (int r = 1; r < 4; ++r) {
+                    out.x = out.x + in[r].x * wy[r]; out.y = out.y + in[r].y * wy[r];
+                    out.z = out.z + in[r].z * wy[r]; out.w = out.w + in[r].w * wy[r];
+                }
+                y[(((int64_t)b * OH + oy) * OW + ox) * C4 + c4] = out;
+            }
+        }
     }
 }
 
@@ -273,8 +298,8 @@ extern "C" int vqae_bicubic_up2_f32(const float* x, int B, int H, int W, int C, 
     hipStream_t stream = (hipStream_t)stream_;
     VQAE_REQUIRE(x && y, VQAE_ERR_INVALID, "bicubic_up2: null pointer");
     VQAE_REQUIRE(C % 4 == 0, VQAE_ERR_UNSUPPORTED, "bicubic_up2: channels %d must be a multiple of 4", C);
-    const int64_t total = (int64_t)B * 4 * H * W * (C / 4);
-    if (total == 0) return VQAE_OK;
+    if ((int64_t)B * H * W == 0) return VQAE_OK;
+    const int64_t total = (int64_t)B * (H + 1) * (W + 1) * (C / 4);        // 2x2 output blocks x channel groups
     const unsigned grid = (unsigned)std::min<int64_t>(vqae::ceil_div(total, 256), 256 * 64);
     bicubic_up2_kernel<<<grid, 256, 0, stream>>>((const float4*)x, B, H, W, C / 4, pre_bias, (float4*)y);
     VQAE_LAUNCH_CHECK();

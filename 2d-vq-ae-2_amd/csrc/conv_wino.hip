@@ -1,5 +1,5 @@
 // Winograd F(2x2, 3x3) form of the trunk Fixup blocks, fp32: C = 128 channels on a 32-wide grid (the code-grid
-// resolution) and C = 64 on a 64-wide grid (the level above it):
+// resolution), C = 64 on a 64-wide grid and C = 32 on a 128-wide grid (the levels above it):
 //   conv2 (3x3 circular, conv_block.py:208)  as  Y = A^T [ sum_c (G g G^T) .* (B^T d B) ] A
 // followed, in the same workgroup, by the block's conv3 (+ scale / bias4 / residual) and the NEXT block's conv1 --
 // the same fusion as conv_mfma.hip's TAIL, whose tail this kernel repeats.
@@ -11,9 +11,10 @@
 // weights on the host), a few VALU instructions per element.  Result differs from the direct form by fp32 rounding
 // only (measured in tests/test_model_gpu.py::test_winograd_trunk_equals_direct).
 //
-// Work split (written for C = 128; C = 64 in brackets).  A 256-thread workgroup owns 4 image rows = 128 [256] output
-// pixels = 32 [64] Winograd tiles (2 tile rows x 16 [32] tile columns).  A wave owns 32 output channels and 32 tiles:
-// 4 channel slices x 1 tile group [2 x 2].  The 4x4 transformed domain is walked one row xi at a time (4 passes):
+// Work split (written for C = 128; C = 64 and C = 32 in brackets).  A 256-thread workgroup owns 4 image rows =
+// 128 [256, 512] output pixels = 32 [64, 128] Winograd tiles (2 tile rows x 16 [32, 64] tile columns).  A wave owns 32
+// output channels and 32 tiles: 4 channel slices x 1 tile group [2 x 2, 1 x 4].  The 4x4 transformed domain is walked
+// one row xi at a time (4 passes):
 //   transform  V_xi[nu][tile][c] = (B^T d B)[xi][nu], nu = 0..3, for all 128 input channels -> LDS (4 x 32 x 132 floats);
 //              the input rows come straight from global/L2 (t1 of the block, written by the previous launch)
 //   GEMM       acc[nu] (32 tiles x 32 channels, one 32x32 MFMA tile) += V_xi[nu] x U[xi, nu]^T over K = 128:
@@ -23,6 +24,11 @@
 // so only one 16-register accumulator + 4 x 16 output registers are live and two workgroups fit a CU; while one
 // transforms, the other one's MFMAs run.  Then t2 = ELU(Y + b3a) + b3b goes to LDS as the [128 px][132] A operand of
 // the conv3 / next-conv1 tails.
+//
+// Measured (cfg B, batch 256, `-DVQAE_WINO_TRACE` stamps): a tile costs a wave ~98 k cycles of MFMA issue, ~10 k of VALU
+// (fold 576, ELU 1150, transforms 512 instructions ...; fp32 MFMA and VALU do not co-execute) and ~20 k of exposed
+// waits across its 14 barrier-separated phases; a lone workgroup per CU takes 154 k cycles per tile, two take 260 k for
+// two.  DESIGN.md section 4 has the roofline numbers, section 8 what would move them.
 #include "common.h"
 
 namespace {

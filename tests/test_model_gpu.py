@@ -171,13 +171,13 @@ def test_winograd_trunk_equals_direct(amd, oracle, monkeypatch):
     """The fp32 trunk blocks (C = 128, 32-wide code grid) run conv2 as Winograd F(2x2, 3x3) (csrc/conv_wino.hip);
     VQAE_NO_WINOGRAD=1 keeps the direct implicit GEMM.  Same function, different fp32 rounding: the pre-VQ features
     must agree to ~1e-5 relative after 50 blocks, indices on every row outside the rounding band, the decoder output
-    to <= 1e-5 MSE.  Also at H != W (grid 32 wide, 16 / 64 high) and a batch that is not a multiple of anything."""
+    to <= 1e-5 MSE.  Also at H != W (grid 32 wide, 4 / 16 / 64 high) and batches that are not a multiple of anything."""
     g = load_golden("model_B")
     spec, p = golden_params(oracle, "B", g)
     wino = amd.NativeVQAE(amd.SPECS["B"], p)
     monkeypatch.setenv("VQAE_NO_WINOGRAD", "1")
     direct = amd.NativeVQAE(amd.SPECS["B"], p)
-    for (B, H, W) in ((2, 256, 256), (3, 128, 256), (1, 512, 256)):
+    for (B, H, W) in ((2, 256, 256), (3, 128, 256), (1, 512, 256), (5, 32, 256)):     # last: a 4-row code grid, all wrap
         x = oracle.make_patches(B, 512, 11)[:, :, :H, :W].contiguous().cuda()
         z_w, z_d = wino.encode_features(x), direct.encode_features(x)
         rel = float((z_w - z_d).abs().max() / z_d.abs().max())

@@ -205,7 +205,9 @@ void wino_trunk_kernel(const WinoK p) {
         aq[0] = *reinterpret_cast<const f32x4*>(af);
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu) {
-            f32x16 acc;                                               // one accumulator live at a time (register budget)
+            // One accumulator live at a time (register budget).  A lone dependent chain issues one 32x32x2 MFMA per
+            // ~72 cycles instead of 64; a second (even / odd k-slice) accumulator measured no gain with two waves per SIMD.
+            f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
@@ -287,6 +289,9 @@ void wino_trunk_kernel(const WinoK p) {
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
         const float* a0 = T + (wm * MI * 32 + li) * LDT + 4 * hh;
         const float* b0 = wsrc + (wn * NI) * (KS * 256) + 4 * lane;
+        f32x4 a[2][MI];                                               // A fragments, read one k-slice ahead of their MFMAs
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) a[0][mi] = *reinterpret_cast<const f32x4*>(a0 + mi * 32 * LDT);
 #pragma unroll
         for (int ug = 0; ug < KS / 4; ++ug) {                         // bt[0] = first 4 k-slices: tail_prefetch()
             if (ug + 1 < KS / 4) {
@@ -298,16 +303,19 @@ void wino_trunk_kernel(const WinoK p) {
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                f32x4 a[MI];
+                const int ks = 4 * ug + u;
+                if (ks + 1 < KS) {
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(a0 + mi * 32 * LDT + 8 * (4 * ug + u));
+                    for (int mi = 0; mi < MI; ++mi)
+                        a[(ks + 1) & 1][mi] = *reinterpret_cast<const f32x4*>(a0 + mi * 32 * LDT + 8 * (ks + 1));
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                         for (int ni = 0; ni < NI; ++ni)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(bt[ug & 1][u][ni][r], a[mi][r], acc[mi][ni], 0, 0, 0);
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(bt[ug & 1][u][ni][r], a[ks & 1][mi][r], acc[mi][ni], 0, 0, 0);
             }
         }
     };

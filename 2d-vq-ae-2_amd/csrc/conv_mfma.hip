@@ -20,6 +20,12 @@
 #include "common.h"
 #include <cstdlib>
 
+namespace vqae {
+bool conv_small_k_supported(const vqae_conv_args* a);
+int conv_small_k(const vqae_conv_args* a, const float* x, const float* w, const float* bias_vec, const float* residual,
+                 float* y, hipStream_t stream);
+}  // namespace vqae
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -699,6 +705,9 @@ static int conv2d_impl(const vqae_conv_args* a, const float* x, const float* gat
     int kc;
     const int rc = fill_conv(a, x, w, bias_vec, residual, y, &k, &kc);
     if (rc) return rc;
+    static const bool no_small = getenv("VQAE_NO_SMALL_K") && atoi(getenv("VQAE_NO_SMALL_K"));
+    if (!gate && !no_small && vqae::conv_small_k_supported(a))       // 8-channel level: VALU kernel at the HBM rate
+        return vqae::conv_small_k(a, x, w, bias_vec, residual, y, stream);
     VQAE_REQUIRE((a->pre_mode == VQAE_PRE_CHANNEL_GATE) == (gate != nullptr), VQAE_ERR_INVALID,
                  "conv2d: VQAE_PRE_CHANNEL_GATE and the gate pointer go together (vqae_conv2d_gated_f32)");
     k.gate = gate;

@@ -245,9 +245,111 @@ int stitch_out(const TI* tiles, const int32_t* rc, int64_t total, int th, int tw
     return VQAE_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// 1x1 and 2x2/stride-2 convs with 8 input channels (the stem-width level of the reference default model: conf/model/
+// vq_ae.yaml:24 out_channels 8): K = 8 or 32.  The MFMA engine spends a whole 128-pixel workgroup (gather geometry,
+// LDS staging, a barrier) on one 8-deep K step and runs 7x under the HBM rate there; here a lane owns one output
+// pixel x 4 output channels (lanes of a pixel share its input through L1, stores are contiguous), weights come
+// through scalar loads.  Same pre-op / epilogue contract and order as vqae_conv2d_f32 (conv_mfma.hip).
+// ------------------------------------------------------------------------------------------------
+struct SmallK {
+    const float* __restrict__ x;
+    const float* __restrict__ w;          // packed [cout_pad][taps * 8]
+    const float* __restrict__ bias_vec;
+    const float* residual;
+    float* y;
+    int H, W, Ho, Wo, cout;
+    int64_t M;
+    int pre_mode, has_scale, has_bias_s, has_act, dt;
+    float pre_a, pre_b, scale, bias_s, act_a, act_b;
+};
+
+template <int KS>
+__global__ __launch_bounds__(256)
+void conv_small_k_kernel(const SmallK p) {
+    constexpr int K = KS * KS * 8;
+    const int cg4 = p.cout >> 2;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.M * cg4) return;
+    const int cg = (int)(i % cg4);
+    const int64_t m = i / cg4;
+    const int ox = (int)(m % p.Wo);
+    const int64_t t = m / p.Wo;
+    const int oy = (int)(t % p.Ho);
+    const int64_t b = t / p.Ho;
+    float v[K];
+#pragma unroll
+    for (int tap = 0; tap < KS * KS; ++tap) {
+        const float4* src = reinterpret_cast<const float4*>(
+            p.x + (((b * p.H + (int64_t)oy * KS + tap / KS) * p.W) + (int64_t)ox * KS + tap % KS) * 8);
+        const float4 a = src[0], c = src[1];
+        v[tap * 8 + 0] = a.x; v[tap * 8 + 1] = a.y; v[tap * 8 + 2] = a.z; v[tap * 8 + 3] = a.w;
+        v[tap * 8 + 4] = c.x; v[tap * 8 + 5] = c.y; v[tap * 8 + 6] = c.z; v[tap * 8 + 7] = c.w;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (p.pre_mode != VQAE_PRE_NONE) {
+            v[k] = v[k] + p.pre_a;
+            if (p.pre_mode == VQAE_PRE_BIAS_ELU_BIAS) v[k] = vqae::elu_act(v[k]) + p.pre_b;
+        }
+        v[k] = vqae::round_dt(v[k], p.dt);
+    }
+    float out[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float* wr = p.w + (int64_t)(4 * cg + e) * K;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc = __builtin_fmaf(v[k], wr[k], acc);
+        if (p.bias_vec) acc = acc + p.bias_vec[4 * cg + e];
+        acc = vqae::round_dt(acc, p.dt);
+        if (p.has_scale) { acc = acc * p.scale; acc = acc + p.bias_s; }
+        else if (p.has_bias_s) { acc = acc + p.bias_s; }
+        out[e] = acc;
+    }
+    const int64_t o = m * p.cout + 4 * cg;
+    if (p.residual) {
+        const float4 r = *reinterpret_cast<const float4*>(p.residual + o);
+        out[0] += r.x; out[1] += r.y; out[2] += r.z; out[3] += r.w;
+    }
+    if (p.has_act == VQAE_ACT_SILU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] = out[e] / (1.0f + expf(-out[e]));
+    } else if (p.has_act) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] = vqae::elu_act(out[e] + p.act_a) + p.act_b;
+    }
+    *reinterpret_cast<float4*>(p.y + o) = make_float4(out[0], out[1], out[2], out[3]);
+}
+
 }  // namespace
 
 namespace vqae {
+// 1x1 / stride 1 or 2x2 / stride 2, no padding, cin == 8, cout % 4 == 0: see conv_small_k_kernel.
+bool conv_small_k_supported(const vqae_conv_args* a) {
+    return a->cin == 8 && a->pad == 0 && a->ksize == a->stride && (a->ksize == 1 || a->ksize == 2) && a->cout % 4 == 0 &&
+           a->cout <= 64 && a->pre_mode <= VQAE_PRE_BIAS_ELU_BIAS && a->in_h % a->ksize == 0 && a->in_w % a->ksize == 0;
+}
+
+int conv_small_k(const vqae_conv_args* a, const float* x, const float* w, const float* bias_vec, const float* residual,
+                 float* y, hipStream_t stream) {
+    SmallK p;
+    p.x = x; p.w = w; p.bias_vec = bias_vec; p.residual = residual; p.y = y;
+    p.H = a->in_h; p.W = a->in_w; p.Ho = a->in_h / a->ksize; p.Wo = a->in_w / a->ksize; p.cout = a->cout;
+    p.M = (int64_t)a->batch * p.Ho * p.Wo;
+    p.pre_mode = a->pre_mode; p.has_scale = a->has_scale; p.has_bias_s = a->has_bias_s; p.has_act = a->has_act; p.dt = a->dtype;
+    p.pre_a = a->pre_a; p.pre_b = a->pre_b; p.scale = a->scale; p.bias_s = a->bias_s; p.act_a = a->act_a; p.act_b = a->act_b;
+    const int64_t threads = p.M * (a->cout / 4);
+    if (threads == 0) return VQAE_OK;
+    VQAE_REQUIRE(ceil_div(threads, 256) < (1ll << 31), VQAE_ERR_UNSUPPORTED, "conv_small_k: too many pixels");
+    const unsigned grid = (unsigned)ceil_div(threads, 256);
+    if (a->ksize == 1) conv_small_k_kernel<1><<<grid, 256, 0, stream>>>(p);
+    else conv_small_k_kernel<2><<<grid, 256, 0, stream>>>(p);
+    VQAE_LAUNCH_CHECK();
+    return VQAE_OK;
+}
+
 // internal entry shared with handle.hip: x_kind 0 NHWC f32 / 1 NCHW f32 / 2 u8 NHWC; y_nchw 0/1
 int conv3x3_direct(const void* x, int x_kind, const float* mean255, const float* inv_std255, const float* w,
                    const float* bias, int B, int H, int W, int cin, int cout, float* y, int y_nchw, int dt,

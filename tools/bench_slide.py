@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""BASELINE config #5 shape on one GPU: whole-slide extraction end to end -- uint8 512x512x3 tiles from a DataLoader ->
+device-side normalisation + encoder + VQ (cfg A) -> code tiles stitched into the slide grid on the device -> one HDF5
+file (groups images / masks), then read back and spot-checked.  Prints one JSON line with patches/s of the whole loop.
+
+    python tools/bench_slide.py [--rows 32 --cols 64 --batch 64 --workers 8 --dtype f32]
+
+The tiles come from a small in-memory pool (the synthetic generator of SyntheticSlideDataset would otherwise bound the
+rate on the host); everything downstream of the DataLoader is the product path (vqae_amd.extract_embeddings)."""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import vqae_amd  # noqa: E402
+from vqae_amd import hdf5  # noqa: E402
+from vqae_amd.extract_embeddings import SyntheticSlideDataset, save_encodings_hdf5  # noqa: E402
+from vqae_amd.model import VQAE  # noqa: E402
+
+
+class PooledSlideDataset(SyntheticSlideDataset):
+    """Same item contract; tiles are drawn from a pool generated once."""
+
+    def __init__(self, sizes, patch_size, pool=48, **kw):
+        super().__init__(sizes, patch_size=patch_size, **kw)
+        rng = np.random.Generator(np.random.PCG64(7))
+        h, w = self.patch_size
+        self._pool = torch.from_numpy(rng.integers(0, 256, size=(pool, h, w, 3), dtype=np.uint8))
+        self._labels = torch.from_numpy((rng.random((pool, 1, h, w)) > 0.995).astype(np.uint8))
+
+    def __getitem__(self, index):
+        img_index, r, c = self.locate(index)
+        k = (index * 7) % self._pool.shape[0]
+        return self._pool[k], self._labels[k], (img_index, np.asarray((r, c)), self.image_paths[img_index],
+                                                self.mask_paths[img_index])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=32)
+    ap.add_argument("--cols", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--workers", type=int, default=8)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"])
+    a = ap.parse_args()
+    spec = vqae_amd.SPECS["A"]
+    torch.manual_seed(0)
+    model = VQAE.from_spec(spec).eval()
+    with torch.no_grad():                       # the reference zero-initialises branch_conv3: make the blocks do work
+        for n, p in model.named_parameters():
+            if n.endswith("branch_conv3.weight"):
+                p.normal_(0.0, 0.5 / p.shape[1] ** 0.5)
+    nat = vqae_amd.NativeVQAE(spec, {k: v for k, v in model.state_dict().items()},
+                              compute_dtype=None if a.dtype == "f32" else a.dtype)
+    ds = PooledSlideDataset([(a.rows, a.cols)], patch_size=512, raw=True, names=["slide_000"])
+    calib = torch.stack([ds[i][0] for i in range(4)]).cuda()
+    xf = ((calib.float() - torch.tensor(vqae_amd.extract_embeddings.MEAN).cuda() * 255) /
+          (torch.tensor(vqae_amd.extract_embeddings.STD).cuda() * 255)).permute(0, 3, 1, 2).contiguous()
+    nat.calibrate_codebook(xf, model.state_dict()["encoder.vq_layers.0.embed"])
+    nat.reserve(a.batch, 512, 512)
+    out = os.path.join(tempfile.mkdtemp(prefix="vqae_slide_"), "slide.hdf5")
+    torch.cuda.synchronize()
+    t0 = time.time()
+    save_encodings_hdf5(out, nat, ds, batch_size=a.batch, num_workers=a.workers)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    n = len(ds)
+    r = hdf5.H5Reader(out)
+    grid, mask = r["images"]["slide_000"], r["masks"]["slide_000_mask"]
+    assert grid.shape == (a.rows * 32, a.cols * 32) and mask.shape == grid.shape, (grid.shape, mask.shape)
+    # spot check: tile (r, c) of the file == a direct encode of that tile
+    for (rr, cc) in ((0, 0), (a.rows - 1, a.cols - 1), (a.rows // 2, 3)):
+        tile = ds[rr * a.cols + cc][0][None].cuda()
+        idx = nat.encode_u8(tile)[1][0].cpu().numpy()
+        assert np.array_equal(grid[rr * 32:(rr + 1) * 32, cc * 32:(cc + 1) * 32].astype(np.int64), idx), (rr, cc)
+    print(json.dumps({"workload": f"cfg A slide: {a.rows}x{a.cols} tiles of 512x512x3 uint8 -> [{grid.shape[0]},{grid.shape[1]}] "
+                                  f"{grid.dtype} code grid + mask -> HDF5, batch {a.batch}, {a.workers} loader workers, {a.dtype}",
+                      "patches": n, "seconds": round(dt, 3), "patches_per_s": round(n / dt, 1),
+                      "hdf5_bytes": os.path.getsize(out), "codes_used": int(np.unique(grid).size)}))
+
+
+if __name__ == "__main__":
+    main()

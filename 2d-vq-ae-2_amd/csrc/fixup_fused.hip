@@ -397,6 +397,116 @@ int launch_tiny_r(FusedP& p, hipStream_t stream) {
     return VQAE_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// C = 8 (stem-width level of the reference default model, 512x512 resolution): a VALU kernel.  With 8 channels an
+// MFMA tile is mostly padding (16x16x4: half of N, two k-steps per tap) and the block's 704 MACs per pixel fit the
+// vector ALUs: one thread per output pixel, t1 of the (TH+2) x 34 halo in LDS, the 704 weights in LDS too (read as
+// wave-uniform 128-bit broadcasts), t2 and conv3 stay in registers.  Same rounding points as the MFMA form.
+// ------------------------------------------------------------------------------------------------
+template <int DT>                                                        // autocast rounding points compiled in
+__global__ __launch_bounds__(256)
+void fixup_same_c8_kernel(const FusedP p) {
+    auto RC = [](float v) -> float {
+        if (DT == VQAE_DT_BF16) return (float)(__bf16)v;
+        if (DT == VQAE_DT_F16) return (float)(_Float16)v;
+        return v;
+    };
+    constexpr int TH = 8, HP = (TH + 2) * 34, LDP = 12;              // LDS pixel stride (floats): 48 B, fewer bank conflicts
+    __shared__ __attribute__((aligned(16))) float T1[HP * LDP];
+    __shared__ __attribute__((aligned(16))) float Wl[8 * 8 + 8 * 72 + 8 * 8];
+    const int tid = threadIdx.x;
+    // packed weights: rows = output channels; w1 [8][8], w2 [8][72] (k = tap * 8 + ci), w3 [8][8]
+    for (int i = tid; i < 704; i += 256) Wl[i] = i < 64 ? p.w1[i] : (i < 640 ? p.w2[i - 64] : p.w3[i - 640]);
+    const float* const w1 = Wl;
+    const float* const w2 = Wl + 64;
+    const float* const w3 = Wl + 640;
+    __syncthreads();
+    for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+        const int txi = tile % p.tiles_x;
+        const int tyi = (tile / p.tiles_x) % p.tiles_y;
+        const int b = tile / (p.tiles_x * p.tiles_y);
+        const int ty0 = tyi * TH, tx0 = txi * 32;
+        const float* const xim = p.x + (int64_t)b * p.H * p.W * 8;
+        // ---- P1: t1 = ELU(conv1(ELU(x + b1a) + b1b) + b2a) + b2b on the halo --------------------------------------
+        for (int hp = tid; hp < HP; hp += 256) {
+            const int hy = hp / 34, hx = hp - 34 * hy;
+            int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
+            iy = iy < 0 ? iy + p.H : (iy >= p.H ? iy - p.H : iy);
+            ix = ix < 0 ? ix + p.W : (ix >= p.W ? ix - p.W : ix);
+            const f32x4* src = reinterpret_cast<const f32x4*>(xim + ((int64_t)iy * p.W + ix) * 8);
+            const f32x4 a0 = src[0], a1 = src[1];
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = a0[e]; v[4 + e] = a1[e]; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = RC(elu_act(v[k] + p.b1a) + p.b1b);
+            f32x4 o0, o1;
+#pragma unroll
+            for (int co = 0; co < 8; ++co) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc = __builtin_fmaf(v[k], w1[co * 8 + k], acc);
+                const float t = RC(elu_act(RC(acc) + p.b2a) + p.b2b);
+                if (co < 4) o0[co] = t; else o1[co - 4] = t;
+            }
+            *reinterpret_cast<f32x4*>(T1 + hp * LDP) = o0;
+            *reinterpret_cast<f32x4*>(T1 + hp * LDP + 4) = o1;
+        }
+        __syncthreads();
+        // ---- P2 + P3: one output pixel per thread ------------------------------------------------------------------
+        {
+            const int py = tid >> 5, px = tid & 31;
+            float acc[8];
+#pragma unroll
+            for (int co = 0; co < 8; ++co) acc[co] = 0.f;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const float* tp = T1 + ((py + tap / 3) * 34 + px + tap % 3) * LDP;
+                const f32x4 t0 = *reinterpret_cast<const f32x4*>(tp), t1v = *reinterpret_cast<const f32x4*>(tp + 4);
+                float tv[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { tv[e] = t0[e]; tv[4 + e] = t1v[e]; }
+#pragma unroll
+                for (int co = 0; co < 8; ++co)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[co] = __builtin_fmaf(tv[k], w2[co * 72 + tap * 8 + k], acc[co]);
+            }
+            float t2[8];
+#pragma unroll
+            for (int co = 0; co < 8; ++co) t2[co] = RC(elu_act(RC(acc[co]) + p.b3a) + p.b3b);
+            const int64_t o = (((int64_t)b * p.H + ty0 + py) * p.W + tx0 + px) * 8;
+            const f32x4 r0 = *reinterpret_cast<const f32x4*>(p.x + o), r1 = *reinterpret_cast<const f32x4*>(p.x + o + 4);
+            f32x4 y0, y1;
+#pragma unroll
+            for (int co = 0; co < 8; ++co) {
+                float a3 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a3 = __builtin_fmaf(t2[k], w3[co * 8 + k], a3);
+                float tv = RC(a3) * p.scale;
+                tv = tv + p.b4;
+                tv = tv + (co < 4 ? r0[co] : r1[co - 4]);
+                if (co < 4) y0[co] = tv; else y1[co - 4] = tv;
+            }
+            *reinterpret_cast<f32x4*>(p.y + o) = y0;
+            *reinterpret_cast<f32x4*>(p.y + o + 4) = y1;
+        }
+        __syncthreads();                               // t1 is dead: the next tile may overwrite it
+    }
+}
+
+int launch_c8(FusedP& p, hipStream_t stream) {
+    p.tiles_x = p.W / 32;
+    p.tiles_y = p.H / 8;
+    p.n_tiles = p.B * p.tiles_x * p.tiles_y;
+    int grid = 256 * 8;
+    if (grid > p.n_tiles) grid = p.n_tiles;
+    if (p.dt == VQAE_DT_BF16) fixup_same_c8_kernel<VQAE_DT_BF16><<<grid, 256, 0, stream>>>(p);
+    else if (p.dt == VQAE_DT_F16) fixup_same_c8_kernel<VQAE_DT_F16><<<grid, 256, 0, stream>>>(p);
+    else fixup_same_c8_kernel<VQAE_DT_F32><<<grid, 256, 0, stream>>>(p);
+    VQAE_LAUNCH_CHECK();
+    return VQAE_OK;
+}
+
 template <int C, int TH>
 int launch_fused(FusedP& p, hipStream_t stream) {
     return p.dt ? launch_fused_r<C, TH, true>(p, stream) : launch_fused_r<C, TH, false>(p, stream);
@@ -434,7 +544,8 @@ extern "C" int vqae_fixup_same_block_f32(const float* x, float* y, const float* 
     VQAE_REQUIRE(dtype >= VQAE_DT_F32 && dtype <= VQAE_DT_F16, VQAE_ERR_INVALID, "fixup_same_block: dtype %d", dtype);
     p.dt = dtype;
     static const bool use32 = getenv("VQAE_FUSED_32X32") && atoi(getenv("VQAE_FUSED_32X32"));
-    if (c == 8) return use32 ? launch_fused<8, 8>(p, stream) : launch_tiny<8, 8>(p, stream);
+    static const bool mfma8 = getenv("VQAE_C8_MFMA") && atoi(getenv("VQAE_C8_MFMA"));
+    if (c == 8) return use32 ? launch_fused<8, 8>(p, stream) : (mfma8 ? launch_tiny<8, 8>(p, stream) : launch_c8(p, stream));
     if (c == 16) return use32 ? launch_fused<16, 8>(p, stream) : launch_tiny<16, 8>(p, stream);
     return launch_fused<32, 4>(p, stream);
 }

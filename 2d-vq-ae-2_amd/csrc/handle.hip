@@ -28,6 +28,9 @@ int wino_frag_weight(const float* w_packed_dev, int c, float* out_dev, hipStream
 int wino_trunk_tail(const float* t1, const float* U, const float* w3, float act_a, float act_b, float t_scale, float t_b4,
                     float* xio, const float* w1n, float n_b1a, float n_b1b, float n_b2a, float n_b2b, float* t1_next,
                     int batch, int h, int w, int c, hipStream_t stream);
+bool up_tail_supported(int cb, int co);
+int up_tail(const float* q, const float* s, const float* w3_packed, int B, int H, int W, int cb, int co, float b3a, float b3b,
+            float scale, float b4, float* y, hipStream_t stream);
 int conv3x3_direct(const void* x, int x_kind, const float* mean255, const float* inv_std255, const float* w,
                    const float* bias, int B, int H, int W, int cin, int cout, float* y, int y_nchw, int dt,
                    hipStream_t stream);
@@ -119,6 +122,7 @@ struct vqae_handle {
     bool fuse_trunk = true;                // conv2 + conv3 (+ next conv1) in one launch at the 128-channel trunk
     bool t1_ready = false;                 // buf[1] already holds the current block's t1
     bool up_conv_first = true;             // fp32 up blocks: 1x1 convs before the bicubic resize (they commute)
+    bool fuse_up_tail = true;              // fp32 up blocks at the stem-side levels: resize + ELU + conv3 + skip in one launch
     bool use_wino = true;                  // fp32 trunk blocks (C = 128 on a 32-wide grid, C = 64 on a 64-wide one): Winograd F(2x2,3x3) conv2
     void* idx_scratch = nullptr;           // indices nobody asked for (vqae_forward with idx == NULL)
     size_t idx_scratch_bytes = 0;
@@ -445,6 +449,17 @@ int run_block(vqae_handle* h, const Block& b, const Block* next, int B, int& H, 
         ConvCall sk(B, H, W, b.cin, b.cout, 1, 1, 0, VQAE_PAD_NONE);
         sk.pre(VQAE_PRE_BIAS, b.b1c, 0.f).bias(b.b1d);                                   // skip_conv(inp + b1c) + b1d
         if ((rc = vqae_conv2d_f32(&sk.a, X, b.wskip, nullptr, nullptr, Q, st))) return rc;
+        if (h->fuse_up_tail && vqae::up_tail_supported(b.br, b.cout)) {
+            // stem-side levels: both resizes, the ELU and conv3 in one launch (misc_kernels.hip up_tail_kernel)
+            ConvCall c1(B, H, W, b.cin, b.br, 1, 1, 0, VQAE_PAD_NONE);
+            c1.pre(VQAE_PRE_BIAS_ELU_BIAS, b.b1a, b.b1b).act(b.b2a, b.b2b);
+            if ((rc = vqae_conv2d_f32(&c1.a, X, b.w1, nullptr, nullptr, P, st))) return rc;
+            ConvCall c2(B, H, W, b.br, b.br, 1, 1, 0, VQAE_PAD_NONE);
+            if ((rc = vqae_conv2d_f32(&c2.a, P, b.w2, nullptr, nullptr, R, st))) return rc;
+            if ((rc = vqae::up_tail(R, Q, b.w3, B, H, W, b.br, b.cout, b.b3a, b.b3b, b.scale, b.b4, X, st))) return rc;
+            H *= 2; W *= 2;
+            return VQAE_OK;                                                             // output in buf[0]
+        }
         if ((rc = vqae_bicubic_up2_f32(Q, B, H, W, b.cout, 0.f, R, st))) return rc;
         ConvCall c1(B, H, W, b.cin, b.br, 1, 1, 0, VQAE_PAD_NONE);
         c1.pre(VQAE_PRE_BIAS_ELU_BIAS, b.b1a, b.b1b).act(b.b2a, b.b2b);
@@ -633,6 +648,7 @@ extern "C" int vqae_create(const vqae_config* cfg, const vqae_tensor* tensors, i
     h->fuse_trunk = !(getenv("VQAE_NO_TRUNK_FUSION") && atoi(getenv("VQAE_NO_TRUNK_FUSION")));
     h->up_conv_first = !(getenv("VQAE_NO_UP_REORDER") && atoi(getenv("VQAE_NO_UP_REORDER")));
     h->use_wino = !(getenv("VQAE_NO_WINOGRAD") && atoi(getenv("VQAE_NO_WINOGRAD")));
+    h->fuse_up_tail = !(getenv("VQAE_NO_UP_TAIL_FUSION") && atoi(getenv("VQAE_NO_UP_TAIL_FUSION")));
     h->C = cfg->stem << cfg->n_down;
     h->D = cfg->projection_dim > 0 ? cfg->projection_dim : h->C;
     h->K = cfg->num_embeddings;

@@ -170,6 +170,125 @@ void bicubic_up2_kernel(const float4* __restrict__ x, int B, int H, int W, int C
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Tail of an 'up' Fixup block at the stem-side levels, fused (fp32, conv-before-resize order of handle.hip):
+//   out = conv3(ELU(bicubic_x2(q) + b3a) + b3b) * scale + b4 + bicubic_x2(s)
+// q [B][H][W][CB] = branch_conv2 output at the low resolution, s [B][H][W][CO] = skip_conv output, out [B][2H][2W][CO].
+// Unfused this is two resize launches that write 4x-larger tensors and a 1x1 conv that reads them back (8 GB per call
+// at 256x256x32 for a batch of 256); here a thread owns a 2x2 output block (one shared 4x4 input window per channel
+// group, as bicubic_up2_kernel), applies the ELU and feeds the CB x CO conv3 from registers (weights: LDS broadcasts).
+// ------------------------------------------------------------------------------------------------
+template <int CB, int CO>
+__global__ __launch_bounds__(256, 2)
+void up_tail_kernel(const float4* __restrict__ q, const float4* __restrict__ sk, const float* __restrict__ w3, int B, int H,
+                    int W, float b3a, float b3b, float scale, float b4, float* __restrict__ y) {
+    const float w75[4] = {-0.03515625f, 0.26171875f, 0.87890625f, -0.10546875f};   // even outputs (offset .75)
+    const float w25[4] = {-0.10546875f, 0.87890625f, 0.26171875f, -0.03515625f};   // odd outputs  (offset .25)
+    __shared__ __attribute__((aligned(16))) float Wl[CB * CO];                      // [ci][co]
+    for (int i = threadIdx.x; i < CB * CO; i += 256) Wl[i] = w3[(i % CO) * CB + i / CO];   // packed rows are [co][ci]
+    __syncthreads();
+    const int OW = 2 * W, OH = 2 * H;
+    const int64_t total = (int64_t)B * (H + 1) * (W + 1);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int bj = (int)(i % (W + 1)) - 1;
+        const int64_t t0 = i / (W + 1);
+        const int bi = (int)(t0 % (H + 1)) - 1;
+        const int64_t b = t0 / (H + 1);
+        int xs[4], ys[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int v = bj - 1 + j; xs[j] = v < 0 ? 0 : (v > W - 1 ? W - 1 : v);
+            int u = bi - 1 + j; ys[j] = u < 0 ? 0 : (u > H - 1 ? H - 1 : u);
+        }
+        // out4[a * 2 + c] = resized value at (row 2 bi + 1 + a, column 2 bj + 1 + c) of one channel group
+        auto resize = [&](const float4* __restrict__ src, int C4, int g, float4* out4) {
+            float4 ho[4], he[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float4* row = src + ((b * H + ys[r]) * W) * C4 + g;
+                float4 v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = row[(int64_t)xs[j] * C4];
+                ho[r].x = v[0].x * w25[0]; ho[r].y = v[0].y * w25[0]; ho[r].z = v[0].z * w25[0]; ho[r].w = v[0].w * w25[0];
+                he[r].x = v[0].x * w75[0]; he[r].y = v[0].y * w75[0]; he[r].z = v[0].z * w75[0]; he[r].w = v[0].w * w75[0];
+#pragma unroll
+                for (int j = 1; j < 4; ++j) {
+                    ho[r].x = ho[r].x + v[j].x * w25[j]; ho[r].y = ho[r].y + v[j].y * w25[j];
+                    ho[r].z = ho[r].z + v[j].z * w25[j]; ho[r].w = ho[r].w + v[j].w * w25[j];
+                    he[r].x = he[r].x + v[j].x * w75[j]; he[r].y = he[r].y + v[j].y * w75[j];
+                    he[r].z = he[r].z + v[j].z * w75[j]; he[r].w = he[r].w + v[j].w * w75[j];
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const float* wy = a == 0 ? w25 : w75;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const float4* in = c == 0 ? ho : he;
+                    float4 o;
+                    o.x = in[0].x * wy[0]; o.y = in[0].y * wy[0]; o.z = in[0].z * wy[0]; o.w = in[0].w * wy[0];
+#pragma unroll
+                    for (int r = 1; r < 4; ++r) {
+                        o.x = o.x + in[r].x * wy[r]; o.y = o.y + in[r].y * wy[r];
+                        o.z = o.z + in[r].z * wy[r]; o.w = o.w + in[r].w * wy[r];
+                    }
+                    out4[a * 2 + c] = o;
+                }
+            }
+        };
+        float acc[4][CO];
+#pragma unroll
+        for (int px = 0; px < 4; ++px)
+#pragma unroll
+            for (int co = 0; co < CO; ++co) acc[px][co] = 0.f;
+#pragma unroll 1
+        for (int g = 0; g < CB / 4; ++g) {                              // branch: resize, ELU, conv3
+            float4 r4[4];
+            resize(q, CB / 4, g, r4);
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                const float tv[4] = {vqae::elu_act(r4[px].x + b3a) + b3b, vqae::elu_act(r4[px].y + b3a) + b3b,
+                                     vqae::elu_act(r4[px].z + b3a) + b3b, vqae::elu_act(r4[px].w + b3a) + b3b};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float* wr = Wl + (4 * g + e) * CO;
+#pragma unroll
+                    for (int co = 0; co < CO; ++co) acc[px][co] = __builtin_fmaf(tv[e], wr[co], acc[px][co]);
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < CO / 4; ++g) {                              // skip: resize, + scale / bias4
+            float4 r4[4];
+            resize(sk, CO / 4, g, r4);
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                const float sv[4] = {r4[px].x, r4[px].y, r4[px].z, r4[px].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float tv = acc[px][4 * g + e] * scale;
+                    tv = tv + b4;
+                    acc[px][4 * g + e] = tv + sv[e];
+                }
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int oy = 2 * bi + 1 + a;
+            if (oy < 0 || oy >= OH) continue;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int ox = 2 * bj + 1 + c;
+                if (ox < 0 || ox >= OW) continue;
+                float4* dst = reinterpret_cast<float4*>(y + ((b * OH + oy) * OW + ox) * CO);
+#pragma unroll
+                for (int g = 0; g < CO / 4; ++g)
+                    dst[g] = make_float4(acc[a * 2 + c][4 * g], acc[a * 2 + c][4 * g + 1], acc[a * 2 + c][4 * g + 2], acc[a * 2 + c][4 * g + 3]);
+            }
+        }
+    }
+}
+
 // Batched 2-D transpose: in [B][R][S] -> out [B][S][R]  (NCHW <-> NHWC with R/S = C / H*W).
 __global__ __launch_bounds__(256)
 void transpose_kernel(const float* __restrict__ in, int R, int S, float* __restrict__ out) {
@@ -326,6 +445,22 @@ void conv_small_k_kernel(const SmallK p) {
 }  // namespace
 
 namespace vqae {
+// Fused tail of an 'up' block (up_tail_kernel): (branch channels, out channels) in {(32, 16), (16, 8)}.
+bool up_tail_supported(int cb, int co) { return (cb == 32 && co == 16) || (cb == 16 && co == 8); }
+
+int up_tail(const float* q, const float* s, const float* w3_packed, int B, int H, int W, int cb, int co, float b3a, float b3b,
+            float scale, float b4, float* y, hipStream_t stream) {
+    VQAE_REQUIRE(q && s && w3_packed && y, VQAE_ERR_INVALID, "up_tail: null pointer");
+    VQAE_REQUIRE(up_tail_supported(cb, co), VQAE_ERR_UNSUPPORTED, "up_tail: channels %d -> %d", cb, co);
+    const int64_t total = (int64_t)B * (H + 1) * (W + 1);
+    if ((int64_t)B * H * W == 0) return VQAE_OK;
+    const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(total, 256), 256 * 64);
+    if (cb == 32) up_tail_kernel<32, 16><<<grid, 256, 0, stream>>>((const float4*)q, (const float4*)s, w3_packed, B, H, W, b3a, b3b, scale, b4, y);
+    else up_tail_kernel<16, 8><<<grid, 256, 0, stream>>>((const float4*)q, (const float4*)s, w3_packed, B, H, W, b3a, b3b, scale, b4, y);
+    VQAE_LAUNCH_CHECK();
+    return VQAE_OK;
+}
+
 // 1x1 / stride 1 or 2x2 / stride 2, no padding, cin == 8, cout % 4 == 0: see conv_small_k_kernel.
 bool conv_small_k_supported(const vqae_conv_args* a) {
     return a->cin == 8 && a->pad == 0 && a->ksize == a->stride && (a->ksize == 1 || a->ksize == 2) && a->cout % 4 == 0 &&

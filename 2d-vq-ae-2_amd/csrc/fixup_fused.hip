@@ -45,6 +45,8 @@ struct FusedCfg {
     static constexpr int GPW = (G1 + 3) / 4;           // per wave
     static constexpr int MPW = TH / 4;                 // output image rows (M tiles) per wave
     static constexpr int LDS_FLOATS = 2 * 32 * LDT + 32 * LDW2 + HPP * LDT;
+    // 16x16x4 kernel: 16 weight rows per matrix and exactly HP halo rows: 39.2 KB at C = 16 -> four workgroups per CU
+    static constexpr int LDS_FLOATS_TINY = 2 * 16 * LDT + 16 * LDW2 + HP * LDT;
 };
 
 template <int C, int TH, bool R16>
@@ -236,7 +238,7 @@ template <> struct KVec<16> { typedef f32x4 type; };
 template <> struct KVec<8> { typedef f32x2 type; };
 
 template <int C, int TH, bool R16>
-__global__ __launch_bounds__(256, 3)
+__global__ __launch_bounds__(256, 4)
 void fixup_same_tiny_kernel(const FusedP p) {
     using K = FusedCfg<C, TH>;
     using kvec = typename KVec<C>::type;
@@ -247,9 +249,9 @@ void fixup_same_tiny_kernel(const FusedP p) {
     constexpr int MPW = TH / 4;                         // image rows per wave; 2 M tiles (16 px) each
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* const W1s = lds;                             // [16][LDT]
-    float* const W3s = W1s + 32 * LDT;
-    float* const W2s = W3s + 32 * LDT;                  // [16][LDW2]
-    float* const T1 = W2s + 32 * LDW2;
+    float* const W3s = W1s + 16 * LDT;
+    float* const W2s = W3s + 16 * LDT;                  // [16][LDW2]
+    float* const T1 = W2s + 16 * LDW2;                  // [HP][LDT]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -309,7 +311,8 @@ void fixup_same_tiny_kernel(const FusedP p) {
                 if (n_ok) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        T1[(16 * g + 4 * q + r) * LDT + li] = RND(elu_act(RND(acc[r]) + p.b2a) + p.b2b);
+                        if (16 * g + 4 * q + r < HP)   // rows past the halo are padding of the last 16-pixel group
+                            T1[(16 * g + 4 * q + r) * LDT + li] = RND(elu_act(RND(acc[r]) + p.b2a) + p.b2b);
                 }
             }
         }
@@ -380,7 +383,7 @@ void fixup_same_tiny_kernel(const FusedP p) {
 template <int C, int TH, bool R16>
 int launch_tiny_r(FusedP& p, hipStream_t stream) {
     using K = FusedCfg<C, TH>;
-    constexpr int lds_bytes = K::LDS_FLOATS * (int)sizeof(float);
+    constexpr int lds_bytes = K::LDS_FLOATS_TINY * (int)sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)fixup_same_tiny_kernel<C, TH, R16>,
@@ -390,7 +393,7 @@ int launch_tiny_r(FusedP& p, hipStream_t stream) {
     p.tiles_x = p.W / 32;
     p.tiles_y = p.H / TH;
     p.n_tiles = p.B * p.tiles_x * p.tiles_y;
-    int grid = 256 * 3;
+    int grid = 256 * 4;
     if (grid > p.n_tiles) grid = p.n_tiles;
     fixup_same_tiny_kernel<C, TH, R16><<<grid, 256, lds_bytes, stream>>>(p);
     VQAE_LAUNCH_CHECK();

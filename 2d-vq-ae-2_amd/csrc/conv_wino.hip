@@ -221,7 +221,7 @@ void wino_trunk_kernel(const WinoK p) {
                 if (xi == 3 && s == STEPS - BPF) {                     // main phase has no more loads to issue
                     tail_prefetch(p.w3);
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) res[i] = *reinterpret_cast<const f32x4*>(xrow + (int64_t)(RP * i) * C);
+                    for (int i = 0; i < 16; ++i) res[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xrow + (int64_t)(RP * i) * C));
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -348,7 +348,7 @@ void wino_trunk_kernel(const WinoK p) {
         t = t * p.t_scale;
         t = t + p.t_b4;
         t = t + res[i];
-        *reinterpret_cast<f32x4*>(xrow + (int64_t)(RP * i) * C) = t;
+        __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(xrow + (int64_t)(RP * i) * C));
         if (TAIL == 2) {                                              // next block's conv1 pre-op, back into T in place
 #pragma unroll
             for (int e = 0; e < 4; ++e) t[e] = elu_act(t[e] + p.n_b1a) + p.n_b1b;
@@ -371,7 +371,7 @@ void wino_trunk_kernel(const WinoK p) {
             f32x4 t = *reinterpret_cast<const f32x4*>(trow + RP * i * LDT);
 #pragma unroll
             for (int e = 0; e < 4; ++e) t[e] = elu_act(t[e] + p.n_b2a) + p.n_b2b;
-            *reinterpret_cast<f32x4*>(yrow + (int64_t)(RP * i) * C) = t;
+            __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(yrow + (int64_t)(RP * i) * C));
         }
         STAMP(13);
     }

@@ -44,8 +44,8 @@ struct ConvK {
     int has_scale, has_bias_s, has_act;
     float scale, bias_s, act_a, act_b;
     // fused tail (trunk, C = 128): conv3 of this block [+ conv1 of the next block], see TAIL below
-    const float* __restrict__ w3;        // packed [128][128]
-    const float* __restrict__ w1n;       // packed [128][128] of the NEXT block's conv1 (TAIL == 2)
+    const float* __restrict__ w3;        // [C][C] in MFMA fragment order for this engine (vqae::wino_frag_weight, k-slice SK)
+    const float* __restrict__ w1n;       // same, the NEXT block's conv1 (TAIL == 2)
     float* y2;                           // [M][128]: next block's t1 (TAIL == 2)
     float t_scale, t_b4, n_b1a, n_b1b, n_b2a, n_b2b;
     const float* __restrict__ gate;      // [B][Cin] per-image channel gate (PRE == VQAE_PRE_CHANNEL_GATE; MBConv SE)
@@ -405,13 +405,15 @@ void conv_mfma_kernel(const ConvK p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
             const elem* af = T + (wm * MI * 32 + li) * LDT + (SK / 2) * hh;
-            const float* bf = wsrc + (wn * NI * 32 + li) * CC + (SK / 2) * hh;
+            // fragment order: one wave-wide load = 64 x SK/2 consecutive floats (row-major weights made it touch 32
+            // cache lines; with 16-bit MFMAs the tails were bound by these loads)
+            const float* bf = wsrc + (wn * NI) * (32 * CC) + (SK / 2) * lane;
             constexpr int NG = CC / (4 * SK);               // groups of 4 k-slices
             frag bq[2][4][NI];                              // B fragments, 4 k-slices per group, 2 groups in flight
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) bq[0][u][ni] = P::load_b(bf + ni * 32 * CC + SK * u);
+                for (int ni = 0; ni < NI; ++ni) bq[0][u][ni] = P::load_b(bf + ni * 32 * CC + 32 * SK * u);
 #pragma unroll
             for (int ug = 0; ug < NG; ++ug) {
                 if (ug + 1 < NG) {
@@ -419,7 +421,7 @@ void conv_mfma_kernel(const ConvK p) {
                     for (int u = 0; u < 4; ++u)
 #pragma unroll
                         for (int ni = 0; ni < NI; ++ni)
-                            bq[(ug + 1) & 1][u][ni] = P::load_b(bf + ni * 32 * CC + SK * (4 * (ug + 1) + u));
+                            bq[(ug + 1) & 1][u][ni] = P::load_b(bf + ni * 32 * CC + 32 * SK * (4 * (ug + 1) + u));
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -728,6 +730,13 @@ extern "C" int vqae_conv2d_gated_f32(const vqae_conv_args* a, const float* x, co
 }
 
 namespace vqae {
+// k-slice width of the engine conv_trunk_tail will use for this dtype / channel count (8: fp32 MFMA, 16: 16-bit MFMA);
+// w3 / w1n must be in fragment order for that width
+int conv_tail_kslice(int dtype, int cin) {
+    static const bool no_m16 = getenv("VQAE_NO_MFMA16") && atoi(getenv("VQAE_NO_MFMA16"));
+    return (dtype != VQAE_DT_F32 && cin % 32 == 0 && !no_m16) ? 16 : 8;
+}
+
 // Trunk Fixup block tail fusion (internal to the handle): conv2 (3x3 circular, C = 128, `a` carries its
 // geometry and its ELU epilogue) + conv3 (+ the next block's conv1 when w1n != null).
 //   t1 [M][128] -> xio [M][128] updated in place (block output) and, if w1n, t1_next [M][128].

@@ -79,8 +79,9 @@ template <int C> struct WinoCfg {
 
 // Fragment order of a [C n][C k] matrix: element (n, k) of the 32-row tile n >> 5 and 8-wide k-slice k >> 3 goes to
 // lane (k >> 2 & 1) * 32 + (n & 31), component k & 3 -- what lane (li = n & 31, hh) feeds to MFMA number k & 3 of the slice.
-__device__ __forceinline__ int frag_offset(int n, int k, int c) {
-    return (((n >> 5) * (c / 8) + (k >> 3)) * 64 + ((k >> 2) & 1) * 32 + (n & 31)) * 4 + (k & 3);
+__device__ __forceinline__ int frag_offset(int n, int k, int c, int sk = 8) {   // sk: k-slice width (16 for 16-bit MFMA)
+    const int h = sk / 2;
+    return (((n >> 5) * (c / sk) + k / sk) * 64 + ((k / h) & 1) * 32 + (n & 31)) * h + k % h;
 }
 
 template <int C, int TAIL>
@@ -405,10 +406,10 @@ __global__ void wino_weight_kernel(const float* __restrict__ w, int c, float* __
 }
 
 // packed [c n][c k] (vqae_conv_pack_weight_f32) -> fragment order
-__global__ void frag_weight_kernel(const float* __restrict__ w, int c, float* __restrict__ out) {
+__global__ void frag_weight_kernel(const float* __restrict__ w, int c, int sk, float* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= c * c) return;
-    out[frag_offset(i / c, i % c, c)] = w[i];
+    out[frag_offset(i / c, i % c, c, sk)] = w[i];
 }
 
 template <int C>
@@ -448,9 +449,9 @@ int wino_transform_weight(const float* w_oihw_dev, int c, float* U_dev, hipStrea
     return VQAE_OK;
 }
 
-// packed [c][c] 1x1 weights (device) -> fragment order (device)
-int wino_frag_weight(const float* w_packed_dev, int c, float* out_dev, hipStream_t stream) {
-    frag_weight_kernel<<<(unsigned)ceil_div(c * c, 256), 256, 0, stream>>>(w_packed_dev, c, out_dev);
+// packed [c][c] 1x1 weights (device) -> fragment order (device); sk = 8 (fp32 MFMA k-slice) or 16 (16-bit MFMA)
+int wino_frag_weight(const float* w_packed_dev, int c, int sk, float* out_dev, hipStream_t stream) {
+    frag_weight_kernel<<<(unsigned)ceil_div(c * c, 256), 256, 0, stream>>>(w_packed_dev, c, sk, out_dev);
     VQAE_LAUNCH_CHECK();
     return VQAE_OK;
 }

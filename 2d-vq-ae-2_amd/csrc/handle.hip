@@ -24,7 +24,8 @@ int conv_trunk_tail(const vqae_conv_args* a, const float* t1, const float* w2, c
 bool wino_trunk_supported(int c, int h, int w);
 size_t wino_weight_floats(int c);
 int wino_transform_weight(const float* w_oihw_dev, int c, float* U_dev, hipStream_t stream);
-int wino_frag_weight(const float* w_packed_dev, int c, float* out_dev, hipStream_t stream);
+int wino_frag_weight(const float* w_packed_dev, int c, int sk, float* out_dev, hipStream_t stream);
+int conv_tail_kslice(int dtype, int cin);
 int wino_trunk_tail(const float* t1, const float* U, const float* w3, float act_a, float act_b, float t_scale, float t_b4,
                     float* xio, const float* w1n, float n_b1a, float n_b1b, float n_b2a, float n_b2b, float* t1_next,
                     int batch, int h, int w, int c, hipStream_t stream);
@@ -91,7 +92,7 @@ struct Block {
     float b1a, b1b, b2a, b2b, b3a, b3b, b4, scale, b1c, b1d;
     float *w1, *w2, *w3, *wskip;          // packed, device
     float* wU = nullptr;                  // Winograd-domain conv2 weights [16][C][C] (fp32 trunk blocks, C = 64 / 128, conv_wino.hip)
-    float *w1f = nullptr, *w3f = nullptr; // conv1 / conv3 weights in MFMA fragment order for that kernel's tails
+    float *w1f = nullptr, *w3f = nullptr; // conv1 / conv3 weights in MFMA fragment order for the fused tails (both trunk kernels)
     // MBConv (conv_block.py:240-321), BatchNorms folded: br = expanded width, w2 = depthwise taps [k*k][br]
     int kind = VQAE_BLOCK_FIXUP, hidden = 0;
     float *bv1 = nullptr, *bv2 = nullptr, *bv3 = nullptr;                        // folded BN shifts
@@ -225,11 +226,12 @@ int load_block(vqae_handle* h, const TensorMap& tm, const std::string& pre, int 
     if (wino && (rc = upload_wino(h, p, cin, &b->wU))) return rc;
     if ((rc = find(tm, pre + ".branch_conv3.weight", (int64_t)cout * b->br, &p))) return rc;
     if ((rc = upload_packed(h, p, cout, b->br, 1, &b->w3))) return rc;
-    if (wino) {
+    if (wino || (mode == MODE_SAME && (cin == 128 || cin == 64) && cout == cin)) {      // blocks that run a fused-tail kernel
+        const int sk = wino ? 8 : vqae::conv_tail_kslice(h->cfg.compute_dtype, cin);
         void *f1, *f3;
         if ((rc = dev_alloc(h, (size_t)cin * cin * 4, &f1)) || (rc = dev_alloc(h, (size_t)cin * cin * 4, &f3))) return rc;
         b->w1f = (float*)f1; b->w3f = (float*)f3;
-        if ((rc = vqae::wino_frag_weight(b->w1, cin, b->w1f, nullptr)) || (rc = vqae::wino_frag_weight(b->w3, cin, b->w3f, nullptr))) return rc;
+        if ((rc = vqae::wino_frag_weight(b->w1, cin, sk, b->w1f, nullptr)) || (rc = vqae::wino_frag_weight(b->w3, cin, sk, b->w3f, nullptr))) return rc;
         VQAE_HIP_CHECK(hipDeviceSynchronize());
     }
     if (mode != MODE_SAME) {
@@ -397,7 +399,7 @@ int run_block(vqae_handle* h, const Block& b, const Block* next, int B, int& H, 
         }
         ConvCall c2(B, H, W, b.br, b.br, 3, 1, 1, VQAE_PAD_CIRCULAR);
         c2.act(b.b3a, b.b3b);
-        if ((rc = vqae::conv_trunk_tail(&c2.a, P, b.w2, b.w3, b.scale, b.b4, X, chain ? next->w1 : nullptr,
+        if ((rc = vqae::conv_trunk_tail(&c2.a, P, b.w2, b.w3f, b.scale, b.b4, X, chain ? next->w1f : nullptr,
                                         chain ? next->b1a : 0.f, chain ? next->b1b : 0.f, chain ? next->b2a : 0.f,
                                         chain ? next->b2b : 0.f, chain ? Q : nullptr, st))) return rc;
         if (chain) std::swap(h->buf[1], h->buf[2]);

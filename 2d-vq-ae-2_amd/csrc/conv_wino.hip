@@ -84,10 +84,25 @@ __device__ __forceinline__ int frag_offset(int n, int k, int c, int sk = 8) {   
     return (((n >> 5) * (c / sk) + k / sk) * 64 + ((k / h) & 1) * 32 + (n & 31)) * h + k % h;
 }
 
-template <int C, int TAIL>
+// DT: autocast rounding points compiled in (16-bit modes, C = 32 only: every conv operand and conv output is rounded
+// to bf16 / f16, the arithmetic stays fp32 -- conv(x16, w16) accumulated in fp32 is what torch.autocast computes, and its
+// Winograd form differs from the direct one by fp32 rounding only).
+template <int C, int TAIL, int DT>
 __global__ __launch_bounds__(256, 2)
 void wino_trunk_kernel(const WinoK p) {
     using K = WinoCfg<C>;
+    auto rnd = [](float v) -> float {
+        if (DT == VQAE_DT_BF16) return (float)(__bf16)v;
+        if (DT == VQAE_DT_F16) return (float)(_Float16)v;
+        return v;
+    };
+    auto rnd4 = [&](f32x4 v) -> f32x4 {
+        if (DT != VQAE_DT_F32) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = rnd(v[e]);
+        }
+        return v;
+    };
     constexpr int W = K::W, PX = K::PX, TC = K::TC, NS = K::NS, KS = K::KS, C4 = K::C4, RP = K::RP, LDT = K::LDT, WN = K::WN;
     constexpr int MI = K::MI, NI = K::NI;
     constexpr int STEPS = 4 * KS;                                    // k-slices per pass (4 nu)
@@ -143,8 +158,8 @@ void wino_trunk_kernel(const WinoK p) {
         for (int s_c = 0; s_c < 2; ++s_c)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                la[s_c][j] = *reinterpret_cast<const f32x4*>(xim + roff[s_r][ra] + coff[s_c][j]);
-                lb[s_c][j] = *reinterpret_cast<const f32x4*>(xim + roff[s_r][rb] + coff[s_c][j]);
+                la[s_c][j] = rnd4(*reinterpret_cast<const f32x4*>(xim + roff[s_r][ra] + coff[s_c][j]));   // conv2 input cast
+                lb[s_c][j] = rnd4(*reinterpret_cast<const f32x4*>(xim + roff[s_r][rb] + coff[s_c][j]));
             }
     };
     auto tr_combine = [&](int xi, int s_r) {
@@ -264,10 +279,10 @@ void wino_trunk_kernel(const WinoK p) {
             f32x4 o00, o01, o10, o11;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                o00[e] = elu_act(y00[4 * g + e] + p.act_a) + p.act_b;
-                o01[e] = elu_act(y01[4 * g + e] + p.act_a) + p.act_b;
-                o10[e] = elu_act(y10[4 * g + e] + p.act_a) + p.act_b;
-                o11[e] = elu_act(y11[4 * g + e] + p.act_a) + p.act_b;
+                o00[e] = rnd(elu_act(rnd(y00[4 * g + e]) + p.act_a) + p.act_b);   // conv2 output cast, conv3 input cast
+                o01[e] = rnd(elu_act(rnd(y01[4 * g + e]) + p.act_a) + p.act_b);
+                o10[e] = rnd(elu_act(rnd(y10[4 * g + e]) + p.act_a) + p.act_b);
+                o11[e] = rnd(elu_act(rnd(y11[4 * g + e]) + p.act_a) + p.act_b);
             }
             *reinterpret_cast<f32x4*>(d + 8 * g) = o00;
             *reinterpret_cast<f32x4*>(d + 8 * g + LDT) = o01;
@@ -345,14 +360,14 @@ void wino_trunk_kernel(const WinoK p) {
     // out = conv3 * scale + bias4 + x, in place over the residual stream, whole pixel rows per RP-th of a workgroup
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        f32x4 t = *reinterpret_cast<const f32x4*>(trow + RP * i * LDT);
+        f32x4 t = rnd4(*reinterpret_cast<const f32x4*>(trow + RP * i * LDT));       // conv3 output cast
         t = t * p.t_scale;
         t = t + p.t_b4;
         t = t + res[i];
         __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(xrow + (int64_t)(RP * i) * C));
         if (TAIL == 2) {                                              // next block's conv1 pre-op, back into T in place
 #pragma unroll
-            for (int e = 0; e < 4; ++e) t[e] = elu_act(t[e] + p.n_b1a) + p.n_b1b;
+            for (int e = 0; e < 4; ++e) t[e] = rnd(elu_act(t[e] + p.n_b1a) + p.n_b1b);   // next conv1 input cast
             *reinterpret_cast<f32x4*>(trow + RP * i * LDT) = t;
         }
     }
@@ -371,7 +386,7 @@ void wino_trunk_kernel(const WinoK p) {
         for (int i = 0; i < 16; ++i) {
             f32x4 t = *reinterpret_cast<const f32x4*>(trow + RP * i * LDT);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) t[e] = elu_act(t[e] + p.n_b2a) + p.n_b2b;
+            for (int e = 0; e < 4; ++e) t[e] = elu_act(rnd(t[e]) + p.n_b2a) + p.n_b2b;   // next conv1 output cast
             __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(yrow + (int64_t)(RP * i) * C));
         }
         STAMP(13);
@@ -379,14 +394,14 @@ void wino_trunk_kernel(const WinoK p) {
 }
 
 // U[xi*4 + nu] = (G g G^T)[xi][nu] for g = w[n][k][3][3];  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
-__global__ void wino_weight_kernel(const float* __restrict__ w, int c, float* __restrict__ U) {
+__global__ void wino_weight_kernel(const float* __restrict__ w, int c, int dt, float* __restrict__ U) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;              // over n * c + k
     if (i >= c * c) return;
     float g[3][3], t[4][3];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
-        for (int b = 0; b < 3; ++b) g[a][b] = w[(int64_t)i * 9 + a * 3 + b];
+        for (int b = 0; b < 3; ++b) g[a][b] = vqae::round_dt(w[(int64_t)i * 9 + a * 3 + b], dt);     // autocast weight cast
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
         t[0][b] = g[0][b];
@@ -412,21 +427,21 @@ __global__ void frag_weight_kernel(const float* __restrict__ w, int c, int sk, f
     out[frag_offset(i / c, i % c, c, sk)] = w[i];
 }
 
-template <int C>
+template <int C, int DT = VQAE_DT_F32>
 int launch_wino(const WinoK& k, bool chain, hipStream_t stream) {
     using K = WinoCfg<C>;
     static bool attr_set = false;
     if (!attr_set) {
-        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)wino_trunk_kernel<C, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES));
-        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)wino_trunk_kernel<C, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES));
+        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)wino_trunk_kernel<C, 1, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES));
+        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)wino_trunk_kernel<C, 2, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES));
         attr_set = true;
     }
     const unsigned grid = (unsigned)(k.M / K::PX);
     // executed matrix work: 16 GEMMs of K = C per 4 output pixels (K_eff = 4 C per pixel) + the 1x1 tails
     const double flops = 2.0 * (double)k.M * C * (4.0 * C + C + (chain ? C : 0));
     vqae::ProfScope prof(C == 128 ? vqae::PROF_CONV3X3_TRUNK : vqae::PROF_NONE, stream, flops);
-    if (chain) wino_trunk_kernel<C, 2><<<grid, 256, K::LDS_BYTES, stream>>>(k);
-    else wino_trunk_kernel<C, 1><<<grid, 256, K::LDS_BYTES, stream>>>(k);
+    if (chain) wino_trunk_kernel<C, 2, DT><<<grid, 256, K::LDS_BYTES, stream>>>(k);
+    else wino_trunk_kernel<C, 1, DT><<<grid, 256, K::LDS_BYTES, stream>>>(k);
     prof.done();
     VQAE_LAUNCH_CHECK();
     return VQAE_OK;
@@ -436,15 +451,19 @@ int launch_wino(const WinoK& k, bool chain, hipStream_t stream) {
 
 namespace vqae {
 
-bool wino_trunk_supported(int c, int h, int w) {
-    return ((c == 128 && w == 32) || (c == 64 && w == 64) || (c == 32 && w == 128)) && h >= 4 && h % 4 == 0;
+// fp32: (C, grid width) in {(128, 32), (64, 64), (32, 128)}; 16-bit autocast modes: (32, 128) only (the wider levels have a
+// 16-bit MFMA kernel with fused tails, conv_mfma.hip)
+bool wino_trunk_supported(int c, int h, int w, int dtype) {
+    const bool shape = dtype == VQAE_DT_F32 ? ((c == 128 && w == 32) || (c == 64 && w == 64) || (c == 32 && w == 128))
+                                            : (c == 32 && w == 128);
+    return shape && h >= 4 && h % 4 == 0;
 }
 
 size_t wino_weight_floats(int c) { return (size_t)16 * c * c; }
 
 // w_oihw_dev [c][c][3][3] (PyTorch layout, device) -> U_dev [16][c][c] (fragment order)
-int wino_transform_weight(const float* w_oihw_dev, int c, float* U_dev, hipStream_t stream) {
-    wino_weight_kernel<<<(unsigned)ceil_div(c * c, 256), 256, 0, stream>>>(w_oihw_dev, c, U_dev);
+int wino_transform_weight(const float* w_oihw_dev, int c, int dtype, float* U_dev, hipStream_t stream) {
+    wino_weight_kernel<<<(unsigned)ceil_div(c * c, 256), 256, 0, stream>>>(w_oihw_dev, c, dtype, U_dev);
     VQAE_LAUNCH_CHECK();
     return VQAE_OK;
 }
@@ -460,10 +479,10 @@ int wino_frag_weight(const float* w_packed_dev, int c, int sk, float* out_dev, h
 // U, w3, w1n in fragment order.
 int wino_trunk_tail(const float* t1, const float* U, const float* w3, float act_a, float act_b, float t_scale, float t_b4,
                     float* xio, const float* w1n, float n_b1a, float n_b1b, float n_b2a, float n_b2b, float* t1_next,
-                    int batch, int h, int w, int c, hipStream_t stream) {
+                    int batch, int h, int w, int c, int dtype, hipStream_t stream) {
     if (batch == 0) return VQAE_OK;
     VQAE_REQUIRE(t1 && U && w3 && xio && (!w1n || t1_next), VQAE_ERR_INVALID, "wino_trunk_tail: null pointer");
-    VQAE_REQUIRE(wino_trunk_supported(c, h, w), VQAE_ERR_UNSUPPORTED, "wino_trunk_tail: C = %d, H = %d, W = %d", c, h, w);
+    VQAE_REQUIRE(wino_trunk_supported(c, h, w, dtype), VQAE_ERR_UNSUPPORTED, "wino_trunk_tail: C = %d, H = %d, W = %d, dtype %d", c, h, w, dtype);
     const int64_t M = (int64_t)batch * h * w;
     VQAE_REQUIRE(M < (1ll << 31) - 256, VQAE_ERR_UNSUPPORTED, "wino_trunk_tail: too many pixels");
     WinoK k;
@@ -477,7 +496,9 @@ int wino_trunk_tail(const float* t1, const float* U, const float* w3, float act_
     if (!trace) (void)hipMalloc((void**)&trace, (size_t)4096 * 128 * 8);
     k.trace = (c == 128 && M / 128 <= 4096) ? trace : nullptr;
 #endif
-    const int rc = c == 128 ? launch_wino<128>(k, w1n != nullptr, stream)
+    const int rc = dtype == VQAE_DT_BF16 ? launch_wino<32, VQAE_DT_BF16>(k, w1n != nullptr, stream)
+                 : dtype == VQAE_DT_F16 ? launch_wino<32, VQAE_DT_F16>(k, w1n != nullptr, stream)
+                 : c == 128 ? launch_wino<128>(k, w1n != nullptr, stream)
                  : (c == 64 ? launch_wino<64>(k, w1n != nullptr, stream) : launch_wino<32>(k, w1n != nullptr, stream));
 #ifdef VQAE_WINO_TRACE
     static int launches = 0;

@@ -21,14 +21,14 @@ char* last_error_buf() {
 int conv_trunk_tail(const vqae_conv_args* a, const float* t1, const float* w2, const float* w3, float t_scale,
                     float t_b4, float* xio, const float* w1n, float n_b1a, float n_b1b, float n_b2a, float n_b2b,
                     float* t1_next, hipStream_t stream);
-bool wino_trunk_supported(int c, int h, int w);
+bool wino_trunk_supported(int c, int h, int w, int dtype);
 size_t wino_weight_floats(int c);
-int wino_transform_weight(const float* w_oihw_dev, int c, float* U_dev, hipStream_t stream);
+int wino_transform_weight(const float* w_oihw_dev, int c, int dtype, float* U_dev, hipStream_t stream);
 int wino_frag_weight(const float* w_packed_dev, int c, int sk, float* out_dev, hipStream_t stream);
 int conv_tail_kslice(int dtype, int cin);
 int wino_trunk_tail(const float* t1, const float* U, const float* w3, float act_a, float act_b, float t_scale, float t_b4,
                     float* xio, const float* w1n, float n_b1a, float n_b1b, float n_b2a, float n_b2b, float* t1_next,
-                    int batch, int h, int w, int c, hipStream_t stream);
+                    int batch, int h, int w, int c, int dtype, hipStream_t stream);
 bool up_tail_supported(int cb, int co);
 int up_tail(const float* q, const float* s, const float* w3_packed, int B, int H, int W, int cb, int co, float b3a, float b3b,
             float scale, float b4, float* y, hipStream_t stream);
@@ -191,7 +191,7 @@ int upload_wino(vqae_handle* h, const float* host, int c, float** out) {
     void* U = nullptr;
     int rc = (e == hipSuccess) ? dev_alloc(h, vqae::wino_weight_floats(c) * 4, &U)
                                : vqae::fail(VQAE_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(e));
-    if (rc == VQAE_OK) rc = vqae::wino_transform_weight((const float*)tmp, c, (float*)U, nullptr);
+    if (rc == VQAE_OK) rc = vqae::wino_transform_weight((const float*)tmp, c, h->cfg.compute_dtype, (float*)U, nullptr);
     if (rc == VQAE_OK && hipDeviceSynchronize() != hipSuccess) rc = vqae::fail(VQAE_ERR_HIP, "winograd weight transform failed");
     (void)hipFree(tmp);
     *out = (float*)U;
@@ -221,8 +221,8 @@ int load_block(vqae_handle* h, const TensorMap& tm, const std::string& pre, int 
     if ((rc = find(tm, pre + ".branch_conv2.weight", (int64_t)b->br * b->br * k2 * k2, &p))) return rc;
     if ((rc = upload_packed(h, p, b->br, b->br, k2, &b->w2))) return rc;
     b->wU = b->w1f = b->w3f = nullptr;
-    const bool wino = mode == MODE_SAME && (cin == 128 || cin == 64 || cin == 32) && cout == cin &&
-                      h->cfg.compute_dtype == VQAE_DT_F32 && h->use_wino;
+    const bool wino = mode == MODE_SAME && cout == cin && h->use_wino &&       // conv_wino.hip: fp32 C = 32/64/128; 16-bit C = 32
+                      (h->cfg.compute_dtype == VQAE_DT_F32 ? (cin == 128 || cin == 64 || cin == 32) : cin == 32);
     if (wino && (rc = upload_wino(h, p, cin, &b->wU))) return rc;
     if ((rc = find(tm, pre + ".branch_conv3.weight", (int64_t)cout * b->br, &p))) return rc;
     if ((rc = upload_packed(h, p, cout, b->br, 1, &b->w3))) return rc;
@@ -379,7 +379,7 @@ int run_block(vqae_handle* h, const Block& b, const Block* next, int B, int& H, 
     if (b.kind == VQAE_BLOCK_MBCONV) return run_mbconv(h, b, B, H, W, st);
     float *X = h->buf[0], *P = h->buf[1], *Q = h->buf[2], *R = h->buf[3];
     int rc;
-    const bool wino = b.mode == MODE_SAME && b.wU && g_dt == VQAE_DT_F32 && h->fuse_trunk && vqae::wino_trunk_supported(b.cin, H, W);
+    const bool wino = b.mode == MODE_SAME && b.wU && h->fuse_trunk && vqae::wino_trunk_supported(b.cin, H, W, g_dt);
     if (b.mode == MODE_SAME && (wino || ((b.cin == 128 || b.cin == 64) && b.cout == b.cin && h->fuse_trunk))) {
         // trunk: conv1 (unless the previous block's tail already produced t1 in P), then ONE launch for
         // conv2 + conv3 (+ the next block's conv1 when it is another 'same' block of this width)
@@ -392,7 +392,7 @@ int run_block(vqae_handle* h, const Block& b, const Block* next, int B, int& H, 
         if (wino) {
             if ((rc = vqae::wino_trunk_tail(P, b.wU, b.w3f, b.b3a, b.b3b, b.scale, b.b4, X, chain ? next->w1f : nullptr,
                                             chain ? next->b1a : 0.f, chain ? next->b1b : 0.f, chain ? next->b2a : 0.f,
-                                            chain ? next->b2b : 0.f, chain ? Q : nullptr, B, H, W, b.cin, st))) return rc;
+                                            chain ? next->b2b : 0.f, chain ? Q : nullptr, B, H, W, b.cin, g_dt, st))) return rc;
             if (chain) std::swap(h->buf[1], h->buf[2]);
             h->t1_ready = chain;
             return VQAE_OK;

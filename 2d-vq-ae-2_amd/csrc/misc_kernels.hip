@@ -175,37 +175,51 @@ void bicubic_up2_kernel(const float4* __restrict__ x, int B, int H, int W, int C
 //   out = conv3(ELU(bicubic_x2(q) + b3a) + b3b) * scale + b4 + bicubic_x2(s)
 // q [B][H][W][CB] = branch_conv2 output at the low resolution, s [B][H][W][CO] = skip_conv output, out [B][2H][2W][CO].
 // Unfused this is two resize launches that write 4x-larger tensors and a 1x1 conv that reads them back (8 GB per call
-// at 256x256x32 for a batch of 256); here a thread owns a 2x2 output block (one shared 4x4 input window per channel
-// group, as bicubic_up2_kernel), applies the ELU and feeds the CB x CO conv3 from registers (weights: LDS broadcasts).
+// at 256x256x32 for a batch of 256).  A workgroup owns 2 x 16 resize blocks = 4 x 32 output pixels:
+//   phase 1  one (block, channel group) item per thread and step: the shared 4x4 input window of the block's 2x2 outputs
+//            (as bicubic_up2_kernel) -> resized values, ELU'd for the branch -> LDS
+//   phase 2  thread = (pixel, half of the output channels): the CB x CO conv3 from LDS (weights: wave-uniform broadcast
+//            reads), + scale / bias4 / resized skip, 128-bit stores.
+// Few registers and 31 KB of LDS per workgroup keep 5 workgroups per CU in flight, which hides the load latency that
+// bound the one-thread-per-block form (1.87 ms).
 // ------------------------------------------------------------------------------------------------
 template <int CB, int CO>
-__global__ __launch_bounds__(256, 2)
+__global__ __launch_bounds__(256)
 void up_tail_kernel(const float4* __restrict__ q, const float4* __restrict__ sk, const float* __restrict__ w3, int B, int H,
-                    int W, float b3a, float b3b, float scale, float b4, float* __restrict__ y) {
+                    int W, int tiles_x, int tiles_y, float b3a, float b3b, float scale, float b4, float* __restrict__ y) {
+    constexpr int LB = CB + 4, LS = CO + 4, GB = CB / 4, GS = CO / 4, NG = GB + GS, HC = CO / 2;
     const float w75[4] = {-0.03515625f, 0.26171875f, 0.87890625f, -0.10546875f};   // even outputs (offset .75)
     const float w25[4] = {-0.10546875f, 0.87890625f, 0.26171875f, -0.03515625f};   // odd outputs  (offset .25)
-    __shared__ __attribute__((aligned(16))) float Wl[CB * CO];                      // [ci][co]
-    for (int i = threadIdx.x; i < CB * CO; i += 256) Wl[i] = w3[(i % CO) * CB + i / CO];   // packed rows are [co][ci]
-    __syncthreads();
+    __shared__ __attribute__((aligned(16))) float Tb[128 * LB];                     // ELU'd resized branch [pixel][ci]
+    __shared__ __attribute__((aligned(16))) float Ts[128 * LS];                     // resized skip [pixel][co]
+    __shared__ __attribute__((aligned(16))) float Wl[CB * CO];                      // conv3 weights [ci][co]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < CB * CO; i += 256) Wl[i] = w3[(i % CO) * CB + i / CO];   // packed rows are [co][ci]
     const int OW = 2 * W, OH = 2 * H;
-    const int64_t total = (int64_t)B * (H + 1) * (W + 1);
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int bj = (int)(i % (W + 1)) - 1;
-        const int64_t t0 = i / (W + 1);
-        const int bi = (int)(t0 % (H + 1)) - 1;
-        const int64_t b = t0 / (H + 1);
-        int xs[4], ys[4];
+    const int n_tiles = B * tiles_x * tiles_y;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int txi = tile % tiles_x;
+        const int tyi = (tile / tiles_x) % tiles_y;
+        const int64_t b = tile / (tiles_x * tiles_y);
+        const int bi0 = 2 * tyi - 1, bj0 = 16 * txi - 1;                            // first resize block of the tile
+        __syncthreads();                                                           // previous tile's phase 2 is done (and Wl is written)
+        // ---- phase 1 ------------------------------------------------------------------------------------------------
+        for (int it = tid; it < 32 * NG; it += 256) {
+            const int g = it % NG, blk = it / NG;
+            const int bi = bi0 + (blk >> 4), bj = bj0 + (blk & 15);
+            const bool branch = g < GB;
+            const float4* src = branch ? q : sk;
+            const int C4 = branch ? GB : GS, gg = branch ? g : g - GB;
+            int xs[4], ys[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int v = bj - 1 + j; xs[j] = v < 0 ? 0 : (v > W - 1 ? W - 1 : v);
-            int u = bi - 1 + j; ys[j] = u < 0 ? 0 : (u > H - 1 ? H - 1 : u);
-        }
-        // out4[a * 2 + c] = resized value at (row 2 bi + 1 + a, column 2 bj + 1 + c) of one channel group
-        auto resize = [&](const float4* __restrict__ src, int C4, int g, float4* out4) {
+            for (int j = 0; j < 4; ++j) {
+                int v = bj - 1 + j; xs[j] = v < 0 ? 0 : (v > W - 1 ? W - 1 : v);
+                int u = bi - 1 + j; ys[j] = u < 0 ? 0 : (u > H - 1 ? H - 1 : u);
+            }
             float4 ho[4], he[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float4* row = src + ((b * H + ys[r]) * W) * C4 + g;
+                const float4* row = src + ((b * H + ys[r]) * W) * C4 + gg;
                 float4 v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = row[(int64_t)xs[j] * C4];
@@ -232,58 +246,50 @@ void up_tail_kernel(const float4* __restrict__ q, const float4* __restrict__ sk,
                         o.x = o.x + in[r].x * wy[r]; o.y = o.y + in[r].y * wy[r];
                         o.z = o.z + in[r].z * wy[r]; o.w = o.w + in[r].w * wy[r];
                     }
-                    out4[a * 2 + c] = o;
-                }
-            }
-        };
-        float acc[4][CO];
-#pragma unroll
-        for (int px = 0; px < 4; ++px)
-#pragma unroll
-            for (int co = 0; co < CO; ++co) acc[px][co] = 0.f;
-#pragma unroll 1
-        for (int g = 0; g < CB / 4; ++g) {                              // branch: resize, ELU, conv3
-            float4 r4[4];
-            resize(q, CB / 4, g, r4);
-#pragma unroll
-            for (int px = 0; px < 4; ++px) {
-                const float tv[4] = {vqae::elu_act(r4[px].x + b3a) + b3b, vqae::elu_act(r4[px].y + b3a) + b3b,
-                                     vqae::elu_act(r4[px].z + b3a) + b3b, vqae::elu_act(r4[px].w + b3a) + b3b};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float* wr = Wl + (4 * g + e) * CO;
-#pragma unroll
-                    for (int co = 0; co < CO; ++co) acc[px][co] = __builtin_fmaf(tv[e], wr[co], acc[px][co]);
+                    const int px = (2 * (blk >> 4) + a) * 32 + 2 * (blk & 15) + c;   // pixel of the 4 x 32 tile
+                    if (branch) {
+                        o.x = vqae::elu_act(o.x + b3a) + b3b; o.y = vqae::elu_act(o.y + b3a) + b3b;
+                        o.z = vqae::elu_act(o.z + b3a) + b3b; o.w = vqae::elu_act(o.w + b3a) + b3b;
+                        *reinterpret_cast<float4*>(Tb + px * LB + 4 * gg) = o;
+                    } else {
+                        *reinterpret_cast<float4*>(Ts + px * LS + 4 * gg) = o;
+                    }
                 }
             }
         }
+        __syncthreads();
+        // ---- phase 2 ------------------------------------------------------------------------------------------------
+        {
+            const int px = tid & 127, half = tid >> 7;                               // half is wave-uniform
+            const int oy = 2 * bi0 + 1 + (px >> 5), ox = 2 * bj0 + 1 + (px & 31);
+            float acc[HC];
 #pragma unroll
-        for (int g = 0; g < CO / 4; ++g) {                              // skip: resize, + scale / bias4
-            float4 r4[4];
-            resize(sk, CO / 4, g, r4);
+            for (int co = 0; co < HC; ++co) acc[co] = 0.f;
 #pragma unroll
-            for (int px = 0; px < 4; ++px) {
-                const float sv[4] = {r4[px].x, r4[px].y, r4[px].z, r4[px].w};
+            for (int c4 = 0; c4 < GB; ++c4) {
+                const float4 t = *reinterpret_cast<const float4*>(Tb + px * LB + 4 * c4);
+                const float tv[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float tv = acc[px][4 * g + e] * scale;
-                    tv = tv + b4;
-                    acc[px][4 * g + e] = tv + sv[e];
+                    const float* wr = Wl + (4 * c4 + e) * CO + HC * half;
+#pragma unroll
+                    for (int co = 0; co < HC; ++co) acc[co] = __builtin_fmaf(tv[e], wr[co], acc[co]);
                 }
             }
-        }
+            if (oy >= 0 && oy < OH && ox >= 0 && ox < OW) {
+                float* dst = y + ((b * OH + oy) * OW + ox) * CO + HC * half;
+                const float* sp = Ts + px * LS + HC * half;
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const int oy = 2 * bi + 1 + a;
-            if (oy < 0 || oy >= OH) continue;
+                for (int g = 0; g < HC / 4; ++g) {
+                    float o[4];
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int ox = 2 * bj + 1 + c;
-                if (ox < 0 || ox >= OW) continue;
-                float4* dst = reinterpret_cast<float4*>(y + ((b * OH + oy) * OW + ox) * CO);
-#pragma unroll
-                for (int g = 0; g < CO / 4; ++g)
-                    dst[g] = make_float4(acc[a * 2 + c][4 * g], acc[a * 2 + c][4 * g + 1], acc[a * 2 + c][4 * g + 2], acc[a * 2 + c][4 * g + 3]);
+                    for (int e = 0; e < 4; ++e) {
+                        float tv = acc[4 * g + e] * scale;
+                        tv = tv + b4;
+                        o[e] = tv + sp[4 * g + e];
+                    }
+                    *reinterpret_cast<float4*>(dst + 4 * g) = make_float4(o[0], o[1], o[2], o[3]);
+                }
             }
         }
     }
@@ -452,11 +458,13 @@ int up_tail(const float* q, const float* s, const float* w3_packed, int B, int H
             float scale, float b4, float* y, hipStream_t stream) {
     VQAE_REQUIRE(q && s && w3_packed && y, VQAE_ERR_INVALID, "up_tail: null pointer");
     VQAE_REQUIRE(up_tail_supported(cb, co), VQAE_ERR_UNSUPPORTED, "up_tail: channels %d -> %d", cb, co);
-    const int64_t total = (int64_t)B * (H + 1) * (W + 1);
     if ((int64_t)B * H * W == 0) return VQAE_OK;
-    const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(total, 256), 256 * 64);
-    if (cb == 32) up_tail_kernel<32, 16><<<grid, 256, 0, stream>>>((const float4*)q, (const float4*)s, w3_packed, B, H, W, b3a, b3b, scale, b4, y);
-    else up_tail_kernel<16, 8><<<grid, 256, 0, stream>>>((const float4*)q, (const float4*)s, w3_packed, B, H, W, b3a, b3b, scale, b4, y);
+    const int tiles_x = (int)ceil_div(W + 1, 16), tiles_y = (int)ceil_div(H + 1, 2);      // 2 x 16 resize blocks per tile
+    const int64_t n_tiles = (int64_t)B * tiles_x * tiles_y;
+    VQAE_REQUIRE(n_tiles < (1ll << 31), VQAE_ERR_UNSUPPORTED, "up_tail: too many tiles");
+    const unsigned grid = (unsigned)std::min<int64_t>(n_tiles, 256 * 40);
+    if (cb == 32) up_tail_kernel<32, 16><<<grid, 256, 0, stream>>>((const float4*)q, (const float4*)s, w3_packed, B, H, W, tiles_x, tiles_y, b3a, b3b, scale, b4, y);
+    else up_tail_kernel<16, 8><<<grid, 256, 0, stream>>>((const float4*)q, (const float4*)s, w3_packed, B, H, W, tiles_x, tiles_y, b3a, b3b, scale, b4, y);
     VQAE_LAUNCH_CHECK();
     return VQAE_OK;
 }

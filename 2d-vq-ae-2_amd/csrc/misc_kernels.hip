@@ -451,8 +451,8 @@ void conv_small_k_kernel(const SmallK p) {
 }  // namespace
 
 namespace vqae {
-// Fused tail of an 'up' block (up_tail_kernel): (branch channels, out channels) in {(32, 16), (16, 8)}.
-bool up_tail_supported(int cb, int co) { return (cb == 32 && co == 16) || (cb == 16 && co == 8); }
+// Fused tail of an 'up' block (up_tail_kernel): (branch channels, out channels) in {(64, 32), (32, 16), (16, 8)}.
+bool up_tail_supported(int cb, int co) { return (cb == 64 && co == 32) || (cb == 32 && co == 16) || (cb == 16 && co == 8); }
 
 int up_tail(const float* q, const float* s, const float* w3_packed, int B, int H, int W, int cb, int co, float b3a, float b3b,
             float scale, float b4, float* y, hipStream_t stream) {
@@ -463,7 +463,8 @@ int up_tail(const float* q, const float* s, const float* w3_packed, int B, int H
     const int64_t n_tiles = (int64_t)B * tiles_x * tiles_y;
     VQAE_REQUIRE(n_tiles < (1ll << 31), VQAE_ERR_UNSUPPORTED, "up_tail: too many tiles");
     const unsigned grid = (unsigned)std::min<int64_t>(n_tiles, 256 * 40);
-    if (cb == 32) up_tail_kernel<32, 16><<<grid, 256, 0, stream>>>((const float4*)q, (const float4*)s, w3_packed, B, H, W, tiles_x, tiles_y, b3a, b3b, scale, b4, y);
+    if (cb == 64) up_tail_kernel<64, 32><<<grid, 256, 0, stream>>>((const float4*)q, (const float4*)s, w3_packed, B, H, W, tiles_x, tiles_y, b3a, b3b, scale, b4, y);
+    else if (cb == 32) up_tail_kernel<32, 16><<<grid, 256, 0, stream>>>((const float4*)q, (const float4*)s, w3_packed, B, H, W, tiles_x, tiles_y, b3a, b3b, scale, b4, y);
     else up_tail_kernel<16, 8><<<grid, 256, 0, stream>>>((const float4*)q, (const float4*)s, w3_packed, B, H, W, tiles_x, tiles_y, b3a, b3b, scale, b4, y);
     VQAE_LAUNCH_CHECK();
     return VQAE_OK;

@@ -278,7 +278,9 @@ void fixup_same_tiny_kernel(const FusedP p) {
     const float* const w1f = W1s + li * LDT + KQ * q;
     const float* const w3f = W3s + li * LDT + KQ * q;
     const float* const w2f = W2s + li * LDW2 + KQ * q;
-    const bool n_ok = li < C;
+    // The weights are the MFMA's row operand, so the accumulator is D[channel 4q + r][pixel li]: a lane owns four
+    // consecutive channels of one pixel and every LDS / global access of the epilogues is 128 bits wide.
+    const bool c_ok = 4 * q < C;                          // C = 8: channel rows 8..15 are padding
 
     for (int t = slot; t < xcd_n; t += per_xcd_wg) {
         const int tile = xcd_lo + t;
@@ -306,13 +308,13 @@ void fixup_same_tiny_kernel(const FusedP p) {
 #pragma unroll
                 for (int k = 0; k < KQ; ++k) {
                     const float av = RND(elu_act(v[k]) + p.b1b);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w1v[k], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1v[k], av, acc, 0, 0, 0);   // D[channel 4q + r][pixel li]
                 }
-                if (n_ok) {
+                if (c_ok && 16 * g + li < HP) {        // rows past the halo are padding of the last 16-pixel group
+                    f32x4 o;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (16 * g + 4 * q + r < HP)   // rows past the halo are padding of the last 16-pixel group
-                            T1[(16 * g + 4 * q + r) * LDT + li] = RND(elu_act(RND(acc[r]) + p.b2a) + p.b2b);
+                    for (int r = 0; r < 4; ++r) o[r] = RND(elu_act(RND(acc[r]) + p.b2a) + p.b2b);
+                    *reinterpret_cast<f32x4*>(T1 + (16 * g + li) * LDT + 4 * q) = o;
                 }
             }
         }
@@ -336,20 +338,21 @@ void fixup_same_tiny_kernel(const FusedP p) {
                     const kvec av = *reinterpret_cast<const kvec*>(T1 + ((ry + dy) * 34 + 16 * hf + li + dx) * LDT + KQ * q);
 #pragma unroll
                     for (int k = 0; k < KQ; ++k)
-                        acc2[mt][hf] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k], bw[k], acc2[mt][hf], 0, 0, 0);
+                        acc2[mt][hf] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[k], av[k], acc2[mt][hf], 0, 0, 0);
                 }
             }
         }
         __syncthreads();
-        if (n_ok) {
+        if (c_ok) {
 #pragma unroll
             for (int mt = 0; mt < MPW; ++mt)
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf)
+                for (int hf = 0; hf < 2; ++hf) {
+                    f32x4 o;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        T1[((wave + 4 * mt) * 32 + 16 * hf + 4 * q + r) * LDT + li] =
-                            RND(elu_act(RND(acc2[mt][hf][r]) + p.b3a) + p.b3b);
+                    for (int r = 0; r < 4; ++r) o[r] = RND(elu_act(RND(acc2[mt][hf][r]) + p.b3a) + p.b3b);
+                    *reinterpret_cast<f32x4*>(T1 + ((wave + 4 * mt) * 32 + 16 * hf + li) * LDT + 4 * q) = o;   // t2 over t1
+                }
         }
         __syncthreads();
 
@@ -363,16 +366,18 @@ void fixup_same_tiny_kernel(const FusedP p) {
                 const kvec av = *reinterpret_cast<const kvec*>(T1 + (ry * 32 + 16 * hf + li) * LDT + KQ * q);
                 f32x4 acc3 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int k = 0; k < KQ; ++k) acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k], w3v[k], acc3, 0, 0, 0);
-                if (n_ok) {
-                    const int64_t base = (((int64_t)b * p.H + ty0 + ry) * p.W + tx0 + 16 * hf + 4 * q) * C + li;
+                for (int k = 0; k < KQ; ++k) acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(w3v[k], av[k], acc3, 0, 0, 0);
+                if (c_ok) {                             // lane: pixel li, channels 4q .. 4q+3 -> one 128-bit load / store
+                    const int64_t base = (((int64_t)b * p.H + ty0 + ry) * p.W + tx0 + 16 * hf + li) * C + 4 * q;
+                    const f32x4 res = *reinterpret_cast<const f32x4*>(p.x + base);
+                    f32x4 o;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float tv = RND(acc3[r]) * p.scale;
                         tv = tv + p.b4;
-                        tv = tv + p.x[base + r * C];
-                        p.y[base + r * C] = tv;
+                        o[r] = tv + res[r];
                     }
+                    *reinterpret_cast<f32x4*>(p.y + base) = o;
                 }
             }
         }

@@ -1,0 +1,238 @@
+// A whole 'down' Fixup block (reference vq_ae/layers/conv_block.py:196-216, mode 'down', fp32) in ONE launch:
+//   t1  = ELU(conv1(ELU(x + b1a) + b1b) + b2a) + b2b          conv1: 1x1, CI -> CO          (CO = 2 CI = branch width)
+//   t2  = ELU(conv2(t1) + b3a) + b3b                          conv2: 2x2 / stride 2, CO -> CO
+//   out = conv3(t2) * scale + b4 + skip_conv(x + b1c) + b1d   conv3: 1x1; skip_conv: 2x2 / stride 2, CI -> CO
+// Unfused the four convs are HBM-bound launches that move 9.7 GB per call at the stem-side level (batch 256): t1 alone is
+// written and read back at twice the input's size.  Here the block reads x and writes out: 1.6 GB.
+//
+// A 256-thread workgroup owns TPX = 4096 / CO output pixels (whole 32-pixel output rows: 4, 2 or 1 of them) and their
+// 2x2 input patches.  All four GEMMs run on v_mfma_f32_32x32x2_f32 with the WEIGHTS as the row operand, so a lane holds
+// four consecutive channels of one pixel and every LDS / global access of the epilogues is 128 bits wide:
+//   phase 1  conv1 on the 4 TPX input pixels straight from global (pre-op in registers) -> t1 into LDS in conv2's operand
+//            layout T1[out pixel][tap * CO + c]
+//   phase 2  conv2 from T1 (K = 4 CO)                              -> t2 into LDS T2[out pixel][c] (over T1)
+//   phase 3  conv3 from T2 and skip_conv from global, epilogue, store.
+// Weight matrices are read from L2 in MFMA fragment order (contiguous wave-wide loads, see conv_wino.hip).
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+using vqae::elu_act;
+
+struct DownK {
+    const float* __restrict__ x;         // [B][H][W][CI]
+    const float* __restrict__ w1;        // fragment order, [CO][CI]
+    const float* __restrict__ w2;        // fragment order, [CO][4 CO]  (k = tap * CO + c)
+    const float* __restrict__ w3;        // fragment order, [CO][CO]
+    const float* __restrict__ wsk;       // fragment order, [CO][4 CI]  (k = tap * CI + c)
+    float* __restrict__ y;               // [B][H/2][W/2][CO]
+    int H, W;                            // input size; W / 2 is a multiple of 32
+    int tiles_x, tiles_y;                // tiles of ROWS x 32 output pixels
+    float b1a, b1b, b2a, b2b, b3a, b3b, b4, scale, b1c, b1d;
+};
+
+template <int CI>
+__global__ __launch_bounds__(256, 2)
+void down_block_kernel(const DownK p) {
+    constexpr int CO = 2 * CI;
+    constexpr int TPX = 4096 / CO;                    // output pixels per workgroup
+    constexpr int ROWS = TPX / 32;                    // output rows per workgroup
+    constexpr int NT = CO / 32;                       // 32-channel output tiles
+    constexpr int LD1 = 4 * CO + 4;                   // T1 row stride (floats)
+    constexpr int LD2 = CO + 4;                       // T2 row stride
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // T1[TPX][LD1]  /  T2[TPX][LD2]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, hh = lane >> 5;
+
+    const int tile = blockIdx.x;
+    const int txi = tile % p.tiles_x;
+    const int tyi = (tile / p.tiles_x) % p.tiles_y;
+    const int64_t b = tile / (p.tiles_x * p.tiles_y);
+    const int oy0 = tyi * ROWS, ox0 = txi * 32;
+    const int Ho = p.H / 2, Wo = p.W / 2;
+    const float* const xim = p.x + b * (int64_t)p.H * p.W * CI;
+
+    // fragment-order weights: [n-tile][k-slice][lane][4]
+    auto wfrag = [&](const float* __restrict__ w, int ks_total, int ct, int u) -> f32x4 {
+        return *reinterpret_cast<const f32x4*>(w + ((int64_t)(ct * ks_total + u) * 64 + lane) * 4);
+    };
+
+    // ---- phase 1: conv1 on the 2 ROWS x 64 input pixels -> T1 ----------------------------------------------------------
+    float* const T1 = lds;
+#pragma unroll 1
+    for (int item = wave; item < (TPX / 8) * NT; item += 4) {
+        const int pg = item / NT, ct = item % NT;      // 32-pixel group of an input row, output-channel tile
+        const int irow = pg >> 1, ix = (pg & 1) * 32 + li;
+        const float* src = xim + ((int64_t)(2 * oy0 + irow) * p.W + 2 * ox0 + ix) * CI + 4 * hh;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int u = 0; u < CI / 8; ++u) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(src + 8 * u);
+            const f32x4 wv = wfrag(p.w1, CI / 8, ct, u);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = elu_act(v[e] + p.b1a) + p.b1b;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[r], v[r], acc, 0, 0, 0);   // D[channel][pixel]
+        }
+        float* dst = T1 + ((irow >> 1) * 32 + (ix >> 1)) * LD1 + ((irow & 1) * 2 + (ix & 1)) * CO + 32 * ct + 4 * hh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = elu_act(acc[4 * g + e] + p.b2a) + p.b2b;
+            *reinterpret_cast<f32x4*>(dst + 8 * g) = o;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: conv2 (K = 4 CO) from T1; phase 3 operands -------------------------------------------------------------
+    const int pg2 = wave / NT, ct = wave % NT;         // this wave's 32 output pixels and 32 output channels
+    const int px = 32 * pg2 + li;                       // output pixel within the tile
+    const int oy = oy0 + (px >> 5), ox = ox0 + (px & 31);
+    f32x16 acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+    {
+        const float* a0 = T1 + px * LD1 + 4 * hh;
+        constexpr int KS = 4 * CO / 8;
+        f32x4 wq[2], aq[2];
+        wq[0] = wfrag(p.w2, KS, ct, 0);
+        aq[0] = *reinterpret_cast<const f32x4*>(a0);
+#pragma unroll
+        for (int u = 0; u < KS; ++u) {
+            if (u + 1 < KS) {
+                wq[(u + 1) & 1] = wfrag(p.w2, KS, ct, u + 1);
+                aq[(u + 1) & 1] = *reinterpret_cast<const f32x4*>(a0 + 8 * (u + 1));
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[u & 1][r], aq[u & 1][r], acc2, 0, 0, 0);
+        }
+    }
+    // skip_conv (K = 4 CI) straight from global while the other waves finish conv2
+    f32x16 accs;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accs[r] = 0.f;
+    {
+        constexpr int KS = 4 * CI / 8;
+#pragma unroll
+        for (int u = 0; u < KS; ++u) {
+            const int tap = u / (CI / 8), s = u % (CI / 8);
+            f32x4 v = *reinterpret_cast<const f32x4*>(xim + ((int64_t)(2 * oy + (tap >> 1)) * p.W + 2 * ox + (tap & 1)) * CI + 8 * s + 4 * hh);
+            const f32x4 wv = wfrag(p.wsk, KS, ct, u);
+            v = v + p.b1c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) accs = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[r], v[r], accs, 0, 0, 0);
+        }
+    }
+    __syncthreads();                                    // every wave is done reading T1
+    float* const T2 = lds;
+    {
+        float* dst = T2 + px * LD2 + 32 * ct + 4 * hh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = elu_act(acc2[4 * g + e] + p.b3a) + p.b3b;
+            *reinterpret_cast<f32x4*>(dst + 8 * g) = o;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: conv3 from T2, epilogue ------------------------------------------------------------------------------------
+    f32x16 acc3;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc3[r] = 0.f;
+    {
+        const float* a0 = T2 + px * LD2 + 4 * hh;
+        constexpr int KS = CO / 8;
+#pragma unroll
+        for (int u = 0; u < KS; ++u) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(a0 + 8 * u);
+            const f32x4 wv = wfrag(p.w3, KS, ct, u);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[r], av[r], acc3, 0, 0, 0);
+        }
+    }
+    float* out = p.y + ((b * Ho + oy) * Wo + ox) * CO + 32 * ct + 4 * hh;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = acc3[4 * g + e] * p.scale;        // branch: conv3 * scale + bias4
+            t = t + p.b4;
+            o[e] = t + (accs[4 * g + e] + p.b1d);       // + skip_conv(x + b1c) + b1d
+        }
+        *reinterpret_cast<f32x4*>(out + 8 * g) = o;
+    }
+}
+
+// packed [n][K] (vqae_conv_pack_weight_f32: K = taps * cin, tap-major) -> MFMA fragment order [n-tile][k-slice][lane][4]
+__global__ void frag_rect_kernel(const float* __restrict__ w, int n_rows, int K, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows * K) return;
+    const int n = i / K, k = i % K;
+    out[(((n >> 5) * (K / 8) + (k >> 3)) * 64 + ((k >> 2) & 1) * 32 + (n & 31)) * 4 + (k & 3)] = w[i];
+}
+
+template <int CI>
+int launch_down(const DownK& k, int64_t n_tiles, hipStream_t stream) {
+    constexpr int CO = 2 * CI, TPX = 4096 / CO;
+    constexpr int lds_bytes = TPX * (4 * CO + 4) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)down_block_kernel<CI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        attr_set = true;
+    }
+    down_block_kernel<CI><<<(unsigned)n_tiles, 256, lds_bytes, stream>>>(k);
+    VQAE_LAUNCH_CHECK();
+    return VQAE_OK;
+}
+
+}  // namespace
+
+namespace vqae {
+
+// cin in {16, 32, 64}; output width a multiple of 32, output height a multiple of the tile's rows (4, 2, 1)
+bool down_block_supported(int cin, int h, int w) {
+    if (cin != 16 && cin != 32 && cin != 64) return false;
+    const int rows = (4096 / (2 * cin)) / 32;
+    return h % 2 == 0 && w % 64 == 0 && (h / 2) % rows == 0;
+}
+
+// packed [n_rows][K] -> fragment order (n_rows % 32 == 0, K % 8 == 0)
+int frag_weight_rect(const float* w_packed_dev, int n_rows, int K, float* out_dev, hipStream_t stream) {
+    VQAE_REQUIRE(n_rows % 32 == 0 && K % 8 == 0, VQAE_ERR_INVALID, "frag_weight_rect: %d x %d", n_rows, K);
+    frag_rect_kernel<<<(unsigned)ceil_div((int64_t)n_rows * K, 256), 256, 0, stream>>>(w_packed_dev, n_rows, K, out_dev);
+    VQAE_LAUNCH_CHECK();
+    return VQAE_OK;
+}
+
+// x [B][H][W][cin] -> y [B][H/2][W/2][2 cin]; weights in fragment order (frag_weight_rect); scalars10 =
+// {b1a, b1b, b2a, b2b, b3a, b3b, b4, scale, b1c, b1d}
+int down_block(const float* x, const float* w1f, const float* w2f, const float* w3f, const float* wskf, int B, int H, int W,
+               int cin, const float* scalars10, float* y, hipStream_t stream) {
+    if (B == 0) return VQAE_OK;
+    VQAE_REQUIRE(x && w1f && w2f && w3f && wskf && y && scalars10, VQAE_ERR_INVALID, "down_block: null pointer");
+    VQAE_REQUIRE(down_block_supported(cin, H, W), VQAE_ERR_UNSUPPORTED, "down_block: cin %d, %dx%d", cin, H, W);
+    DownK k;
+    k.x = x; k.w1 = w1f; k.w2 = w2f; k.w3 = w3f; k.wsk = wskf; k.y = y;
+    k.H = H; k.W = W;
+    const int rows = (4096 / (2 * cin)) / 32;
+    k.tiles_x = (W / 2) / 32; k.tiles_y = (H / 2) / rows;
+    k.b1a = scalars10[0]; k.b1b = scalars10[1]; k.b2a = scalars10[2]; k.b2b = scalars10[3]; k.b3a = scalars10[4];
+    k.b3b = scalars10[5]; k.b4 = scalars10[6]; k.scale = scalars10[7]; k.b1c = scalars10[8]; k.b1d = scalars10[9];
+    const int64_t n_tiles = (int64_t)B * k.tiles_x * k.tiles_y;
+    VQAE_REQUIRE(n_tiles < (1ll << 31), VQAE_ERR_UNSUPPORTED, "down_block: too many tiles");
+    if (cin == 16) return launch_down<16>(k, n_tiles, stream);
+    if (cin == 32) return launch_down<32>(k, n_tiles, stream);
+    return launch_down<64>(k, n_tiles, stream);
+}
+
+}  // namespace vqae

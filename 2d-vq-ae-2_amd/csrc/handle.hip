@@ -29,6 +29,10 @@ int conv_tail_kslice(int dtype, int cin);
 int wino_trunk_tail(const float* t1, const float* U, const float* w3, float act_a, float act_b, float t_scale, float t_b4,
                     float* xio, const float* w1n, float n_b1a, float n_b1b, float n_b2a, float n_b2b, float* t1_next,
                     int batch, int h, int w, int c, int dtype, hipStream_t stream);
+bool down_block_supported(int cin, int h, int w);
+int frag_weight_rect(const float* w_packed_dev, int n_rows, int K, float* out_dev, hipStream_t stream);
+int down_block(const float* x, const float* w1f, const float* w2f, const float* w3f, const float* wskf, int B, int H, int W,
+               int cin, const float* scalars10, float* y, hipStream_t stream);
 bool up_tail_supported(int cb, int co);
 int up_tail(const float* q, const float* s, const float* w3_packed, int B, int H, int W, int cb, int co, float b3a, float b3b,
             float scale, float b4, float* y, hipStream_t stream);
@@ -93,6 +97,7 @@ struct Block {
     float *w1, *w2, *w3, *wskip;          // packed, device
     float* wU = nullptr;                  // Winograd-domain conv2 weights [16][C][C] (fp32 trunk blocks, C = 64 / 128, conv_wino.hip)
     float *w1f = nullptr, *w3f = nullptr; // conv1 / conv3 weights in MFMA fragment order for the fused tails (both trunk kernels)
+    float *w2f = nullptr, *wskf = nullptr;// 'down' blocks: conv2 / skip_conv in fragment order too (down_fused.hip)
     // MBConv (conv_block.py:240-321), BatchNorms folded: br = expanded width, w2 = depthwise taps [k*k][br]
     int kind = VQAE_BLOCK_FIXUP, hidden = 0;
     float *bv1 = nullptr, *bv2 = nullptr, *bv3 = nullptr;                        // folded BN shifts
@@ -123,6 +128,7 @@ struct vqae_handle {
     bool fuse_trunk = true;                // conv2 + conv3 (+ next conv1) in one launch at the 128-channel trunk
     bool t1_ready = false;                 // buf[1] already holds the current block's t1
     bool up_conv_first = true;             // fp32 up blocks: 1x1 convs before the bicubic resize (they commute)
+    bool fuse_down = true;                 // fp32 'down' blocks (16/32/64 input channels): one launch (down_fused.hip)
     bool fuse_up_tail = true;              // fp32 up blocks at the stem-side levels: resize + ELU + conv3 + skip in one launch
     bool use_wino = true;                  // fp32 trunk blocks (C = 128 on a 32-wide grid, C = 64 on a 64-wide one): Winograd F(2x2,3x3) conv2
     void* idx_scratch = nullptr;           // indices nobody asked for (vqae_forward with idx == NULL)
@@ -239,6 +245,19 @@ int load_block(vqae_handle* h, const TensorMap& tm, const std::string& pre, int 
         const int ks = mode == MODE_DOWN ? 2 : 1;
         if ((rc = find(tm, pre + ".skip_conv.weight", (int64_t)cout * cin * ks * ks, &p))) return rc;
         if ((rc = upload_packed(h, p, cout, cin, ks, &b->wskip))) return rc;
+    }
+    b->w2f = b->wskf = nullptr;
+    if (mode == MODE_DOWN && h->cfg.compute_dtype == VQAE_DT_F32 && h->fuse_down && cout == 2 * cin &&
+        (cin == 16 || cin == 32 || cin == 64)) {             // whole block in one launch (down_fused.hip)
+        struct { float* src; int K; float** dst; } m[4] = {{b->w1, cin, &b->w1f}, {b->w2, 4 * cout, &b->w2f},
+                                                          {b->w3, cout, &b->w3f}, {b->wskip, 4 * cin, &b->wskf}};
+        for (auto& e : m) {
+            void* f;
+            if ((rc = dev_alloc(h, (size_t)cout * e.K * 4, &f))) return rc;
+            *e.dst = (float*)f;
+            if ((rc = vqae::frag_weight_rect(e.src, cout, e.K, *e.dst, nullptr))) return rc;
+        }
+        VQAE_HIP_CHECK(hipDeviceSynchronize());
     }
 #undef S_
     return VQAE_OK;
@@ -424,6 +443,13 @@ int run_block(vqae_handle* h, const Block& b, const Block* next, int B, int& H, 
         ConvCall c3(B, H, W, b.br, b.cout, 1, 1, 0, VQAE_PAD_NONE);
         c3.scale_bias(b.scale, b.b4);
         return vqae_conv2d_f32(&c3.a, Q, b.w3, nullptr, X, X, st);          // + inp, in place
+    }
+    if (b.mode == MODE_DOWN && b.w2f && g_dt == VQAE_DT_F32 && vqae::down_block_supported(b.cin, H, W)) {
+        const float sc[10] = {b.b1a, b.b1b, b.b2a, b.b2b, b.b3a, b.b3b, b.b4, b.scale, b.b1c, b.b1d};
+        if ((rc = vqae::down_block(X, b.w1f, b.w2f, b.w3f, b.wskf, B, H, W, b.cin, sc, R, st))) return rc;
+        H /= 2; W /= 2;
+        std::swap(h->buf[0], h->buf[3]);
+        return VQAE_OK;
     }
     if (b.mode == MODE_DOWN) {
         ConvCall sk(B, H, W, b.cin, b.cout, 2, 2, 0, VQAE_PAD_NONE);         // skip_conv(inp + bias1c) + bias1d
@@ -651,6 +677,7 @@ extern "C" int vqae_create(const vqae_config* cfg, const vqae_tensor* tensors, i
     h->up_conv_first = !(getenv("VQAE_NO_UP_REORDER") && atoi(getenv("VQAE_NO_UP_REORDER")));
     h->use_wino = !(getenv("VQAE_NO_WINOGRAD") && atoi(getenv("VQAE_NO_WINOGRAD")));
     h->fuse_up_tail = !(getenv("VQAE_NO_UP_TAIL_FUSION") && atoi(getenv("VQAE_NO_UP_TAIL_FUSION")));
+    h->fuse_down = !(getenv("VQAE_NO_DOWN_FUSION") && atoi(getenv("VQAE_NO_DOWN_FUSION")));
     h->C = cfg->stem << cfg->n_down;
     h->D = cfg->projection_dim > 0 ? cfg->projection_dim : h->C;
     h->K = cfg->num_embeddings;

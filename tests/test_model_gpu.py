@@ -196,6 +196,27 @@ def test_winograd_trunk_equals_direct(amd, oracle, monkeypatch):
     assert bad_clear == 0 and bad <= max(2, n // 2000), (bad_clear, bad, n)
 
 
+def test_fused_down_and_up_blocks_equal_unfused(amd, oracle, monkeypatch):
+    """'down' blocks in one launch (csrc/down_fused.hip) and the fused 'up' tails (up_tail_kernel) against the
+    conv-by-conv path (VQAE_NO_DOWN_FUSION / VQAE_NO_UP_TAIL_FUSION): same arithmetic, different summation order."""
+    g = load_golden("model_B")
+    spec, p = golden_params(oracle, "B", g)
+    fused = amd.NativeVQAE(amd.SPECS["B"], p)
+    monkeypatch.setenv("VQAE_NO_DOWN_FUSION", "1")
+    monkeypatch.setenv("VQAE_NO_UP_TAIL_FUSION", "1")
+    plain = amd.NativeVQAE(amd.SPECS["B"], p)
+    for (B, H, W) in ((2, 256, 256), (3, 128, 256), (1, 256, 512)):
+        x = oracle.make_patches(B, 512, 13)[:, :, :H, :W].contiguous().cuda()
+        z_f, z_p = fused.encode_features(x), plain.encode_features(x)
+        rel = float((z_f - z_p).abs().max() / z_p.abs().max())
+        q = plain.encode(x)[0]
+        d_f, d_p = fused.decode(q), plain.decode(q)
+        mse = float(((d_f - d_p) ** 2).mean())
+        agree = float((fused.encode(x)[1] == plain.encode(x)[1]).float().mean())
+        print(f"fused down/up vs unfused {B}x{H}x{W}: z rel err {rel:.2e}, idx agreement {agree:.5f}, decoder mse {mse:.2e}")
+        assert rel <= 5e-5 and agree >= 0.999 and mse <= 1e-6
+
+
 @pytest.mark.parametrize("B,H,W", [(1, 32, 32), (3, 64, 96), (5, 96, 32), (2, 128, 128)])
 def test_native_handles_odd_batches_and_non_square_inputs(amd, oracle, B, H, W):
     """Shapes the reference accepts (any H, W multiple of 2**n_down): fused (W % 32 == 0 levels) and

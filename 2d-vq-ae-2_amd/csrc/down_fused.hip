@@ -1,4 +1,4 @@
-// A whole 'down' Fixup block (reference vq_ae/layers/conv_block.py:196-216, mode 'down', fp32) in ONE launch:
+// A whole 'down' Fixup block (reference vq_ae/layers/conv_block.py:196-216, mode 'down') in ONE launch:
 //   t1  = ELU(conv1(ELU(x + b1a) + b1b) + b2a) + b2b          conv1: 1x1, CI -> CO          (CO = 2 CI = branch width)
 //   t2  = ELU(conv2(t1) + b3a) + b3b                          conv2: 2x2 / stride 2, CO -> CO
 //   out = conv3(t2) * scale + b4 + skip_conv(x + b1c) + b1d   conv3: 1x1; skip_conv: 2x2 / stride 2, CI -> CO
@@ -33,9 +33,16 @@ struct DownK {
     float b1a, b1b, b2a, b2b, b3a, b3b, b4, scale, b1c, b1d;
 };
 
-template <int CI>
+// DT: autocast cast points compiled in (every conv operand and conv output rounded to bf16 / f16; weights arrive
+// rounded; products of 16-bit values are exact in the fp32 MFMA, accumulation is fp32 as under torch.autocast)
+template <int CI, int DT>
 __global__ __launch_bounds__(256, 2)
 void down_block_kernel(const DownK p) {
+    auto rnd = [](float v) -> float {
+        if (DT == VQAE_DT_BF16) return (float)(__bf16)v;
+        if (DT == VQAE_DT_F16) return (float)(_Float16)v;
+        return v;
+    };
     constexpr int CO = 2 * CI;
     constexpr int TPX = 4096 / CO;                    // output pixels per workgroup
     constexpr int ROWS = TPX / 32;                    // output rows per workgroup
@@ -76,7 +83,7 @@ void down_block_kernel(const DownK p) {
             f32x4 v = *reinterpret_cast<const f32x4*>(src + 8 * u);
             const f32x4 wv = wfrag(p.w1, CI / 8, ct, u);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = elu_act(v[e] + p.b1a) + p.b1b;
+            for (int e = 0; e < 4; ++e) v[e] = rnd(elu_act(v[e] + p.b1a) + p.b1b);            // conv1 input cast
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[r], v[r], acc, 0, 0, 0);   // D[channel][pixel]
         }
@@ -85,7 +92,7 @@ void down_block_kernel(const DownK p) {
         for (int g = 0; g < 4; ++g) {
             f32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = elu_act(acc[4 * g + e] + p.b2a) + p.b2b;
+            for (int e = 0; e < 4; ++e) o[e] = rnd(elu_act(rnd(acc[4 * g + e]) + p.b2a) + p.b2b);   // conv1 output / conv2 input casts
             *reinterpret_cast<f32x4*>(dst + 8 * g) = o;
         }
     }
@@ -127,6 +134,8 @@ void down_block_kernel(const DownK p) {
             const f32x4 wv = wfrag(p.wsk, KS, ct, u);
             v = v + p.b1c;
 #pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = rnd(v[e]);                                   // skip_conv input cast
+#pragma unroll
             for (int r = 0; r < 4; ++r) accs = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[r], v[r], accs, 0, 0, 0);
         }
     }
@@ -138,7 +147,7 @@ void down_block_kernel(const DownK p) {
         for (int g = 0; g < 4; ++g) {
             f32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = elu_act(acc2[4 * g + e] + p.b3a) + p.b3b;
+            for (int e = 0; e < 4; ++e) o[e] = rnd(elu_act(rnd(acc2[4 * g + e]) + p.b3a) + p.b3b);  // conv2 output / conv3 input casts
             *reinterpret_cast<f32x4*>(dst + 8 * g) = o;
         }
     }
@@ -165,9 +174,9 @@ void down_block_kernel(const DownK p) {
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float t = acc3[4 * g + e] * p.scale;        // branch: conv3 * scale + bias4
+            float t = rnd(acc3[4 * g + e]) * p.scale;   // branch: conv3 * scale + bias4
             t = t + p.b4;
-            o[e] = t + (accs[4 * g + e] + p.b1d);       // + skip_conv(x + b1c) + b1d
+            o[e] = t + (rnd(accs[4 * g + e]) + p.b1d);  // + skip_conv(x + b1c) + b1d
         }
         *reinterpret_cast<f32x4*>(out + 8 * g) = o;
     }
@@ -181,18 +190,25 @@ __global__ void frag_rect_kernel(const float* __restrict__ w, int n_rows, int K,
     out[(((n >> 5) * (K / 8) + (k >> 3)) * 64 + ((k >> 2) & 1) * 32 + (n & 31)) * 4 + (k & 3)] = w[i];
 }
 
-template <int CI>
-int launch_down(const DownK& k, int64_t n_tiles, hipStream_t stream) {
+template <int CI, int DT>
+int launch_down_dt(const DownK& k, int64_t n_tiles, hipStream_t stream) {
     constexpr int CO = 2 * CI, TPX = 4096 / CO;
     constexpr int lds_bytes = TPX * (4 * CO + 4) * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)down_block_kernel<CI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)down_block_kernel<CI, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         attr_set = true;
     }
-    down_block_kernel<CI><<<(unsigned)n_tiles, 256, lds_bytes, stream>>>(k);
+    down_block_kernel<CI, DT><<<(unsigned)n_tiles, 256, lds_bytes, stream>>>(k);
     VQAE_LAUNCH_CHECK();
     return VQAE_OK;
+}
+
+template <int CI>
+int launch_down(const DownK& k, int64_t n_tiles, int dtype, hipStream_t stream) {
+    if (dtype == VQAE_DT_BF16) return launch_down_dt<CI, VQAE_DT_BF16>(k, n_tiles, stream);
+    if (dtype == VQAE_DT_F16) return launch_down_dt<CI, VQAE_DT_F16>(k, n_tiles, stream);
+    return launch_down_dt<CI, VQAE_DT_F32>(k, n_tiles, stream);
 }
 
 }  // namespace
@@ -217,8 +233,9 @@ int frag_weight_rect(const float* w_packed_dev, int n_rows, int K, float* out_de
 // x [B][H][W][cin] -> y [B][H/2][W/2][2 cin]; weights in fragment order (frag_weight_rect); scalars10 =
 // {b1a, b1b, b2a, b2b, b3a, b3b, b4, scale, b1c, b1d}
 int down_block(const float* x, const float* w1f, const float* w2f, const float* w3f, const float* wskf, int B, int H, int W,
-               int cin, const float* scalars10, float* y, hipStream_t stream) {
+               int cin, const float* scalars10, int dtype, float* y, hipStream_t stream) {
     if (B == 0) return VQAE_OK;
+    VQAE_REQUIRE(dtype >= VQAE_DT_F32 && dtype <= VQAE_DT_F16, VQAE_ERR_INVALID, "down_block: dtype %d", dtype);
     VQAE_REQUIRE(x && w1f && w2f && w3f && wskf && y && scalars10, VQAE_ERR_INVALID, "down_block: null pointer");
     VQAE_REQUIRE(down_block_supported(cin, H, W), VQAE_ERR_UNSUPPORTED, "down_block: cin %d, %dx%d", cin, H, W);
     DownK k;
@@ -230,9 +247,9 @@ int down_block(const float* x, const float* w1f, const float* w2f, const float* 
     k.b3b = scalars10[5]; k.b4 = scalars10[6]; k.scale = scalars10[7]; k.b1c = scalars10[8]; k.b1d = scalars10[9];
     const int64_t n_tiles = (int64_t)B * k.tiles_x * k.tiles_y;
     VQAE_REQUIRE(n_tiles < (1ll << 31), VQAE_ERR_UNSUPPORTED, "down_block: too many tiles");
-    if (cin == 16) return launch_down<16>(k, n_tiles, stream);
-    if (cin == 32) return launch_down<32>(k, n_tiles, stream);
-    return launch_down<64>(k, n_tiles, stream);
+    if (cin == 16) return launch_down<16>(k, n_tiles, dtype, stream);
+    if (cin == 32) return launch_down<32>(k, n_tiles, dtype, stream);
+    return launch_down<64>(k, n_tiles, dtype, stream);
 }
 
 }  // namespace vqae

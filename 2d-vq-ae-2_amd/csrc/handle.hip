@@ -32,7 +32,7 @@ int wino_trunk_tail(const float* t1, const float* U, const float* w3, float act_
 bool down_block_supported(int cin, int h, int w);
 int frag_weight_rect(const float* w_packed_dev, int n_rows, int K, float* out_dev, hipStream_t stream);
 int down_block(const float* x, const float* w1f, const float* w2f, const float* w3f, const float* wskf, int B, int H, int W,
-               int cin, const float* scalars10, float* y, hipStream_t stream);
+               int cin, const float* scalars10, int dtype, float* y, hipStream_t stream);
 bool up_tail_supported(int cb, int co);
 int up_tail(const float* q, const float* s, const float* w3_packed, int B, int H, int W, int cb, int co, float b3a, float b3b,
             float scale, float b4, float* y, hipStream_t stream);
@@ -128,7 +128,7 @@ struct vqae_handle {
     bool fuse_trunk = true;                // conv2 + conv3 (+ next conv1) in one launch at the 128-channel trunk
     bool t1_ready = false;                 // buf[1] already holds the current block's t1
     bool up_conv_first = true;             // fp32 up blocks: 1x1 convs before the bicubic resize (they commute)
-    bool fuse_down = true;                 // fp32 'down' blocks (16/32/64 input channels): one launch (down_fused.hip)
+    bool fuse_down = true;                 // 'down' blocks with 16/32/64 input channels: one launch (down_fused.hip)
     bool fuse_up_tail = true;              // fp32 up blocks at the stem-side levels: resize + ELU + conv3 + skip in one launch
     bool use_wino = true;                  // fp32 trunk blocks (C = 128 on a 32-wide grid, C = 64 on a 64-wide one): Winograd F(2x2,3x3) conv2
     void* idx_scratch = nullptr;           // indices nobody asked for (vqae_forward with idx == NULL)
@@ -247,7 +247,7 @@ int load_block(vqae_handle* h, const TensorMap& tm, const std::string& pre, int 
         if ((rc = upload_packed(h, p, cout, cin, ks, &b->wskip))) return rc;
     }
     b->w2f = b->wskf = nullptr;
-    if (mode == MODE_DOWN && h->cfg.compute_dtype == VQAE_DT_F32 && h->fuse_down && cout == 2 * cin &&
+    if (mode == MODE_DOWN && h->fuse_down && cout == 2 * cin &&
         (cin == 16 || cin == 32 || cin == 64)) {             // whole block in one launch (down_fused.hip)
         struct { float* src; int K; float** dst; } m[4] = {{b->w1, cin, &b->w1f}, {b->w2, 4 * cout, &b->w2f},
                                                           {b->w3, cout, &b->w3f}, {b->wskip, 4 * cin, &b->wskf}};
@@ -444,9 +444,9 @@ int run_block(vqae_handle* h, const Block& b, const Block* next, int B, int& H, 
         c3.scale_bias(b.scale, b.b4);
         return vqae_conv2d_f32(&c3.a, Q, b.w3, nullptr, X, X, st);          // + inp, in place
     }
-    if (b.mode == MODE_DOWN && b.w2f && g_dt == VQAE_DT_F32 && vqae::down_block_supported(b.cin, H, W)) {
+    if (b.mode == MODE_DOWN && b.w2f && vqae::down_block_supported(b.cin, H, W)) {
         const float sc[10] = {b.b1a, b.b1b, b.b2a, b.b2b, b.b3a, b.b3b, b.b4, b.scale, b.b1c, b.b1d};
-        if ((rc = vqae::down_block(X, b.w1f, b.w2f, b.w3f, b.wskf, B, H, W, b.cin, sc, R, st))) return rc;
+        if ((rc = vqae::down_block(X, b.w1f, b.w2f, b.w3f, b.wskf, B, H, W, b.cin, sc, g_dt, R, st))) return rc;
         H /= 2; W /= 2;
         std::swap(h->buf[0], h->buf[3]);
         return VQAE_OK;

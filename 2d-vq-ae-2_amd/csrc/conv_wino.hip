@@ -44,7 +44,7 @@ struct WinoK {
     const float* __restrict__ w1n;       // same, the next block's conv1 (TAIL == 2)
     float* xio;                          // [M][C] residual stream, updated in place
     float* y2;                           // [M][C] next block's t1 (TAIL == 2)
-    int H, M;                            // image rows; M = B * H * W
+    int H, Wimg, M;                      // image rows / columns (Wimg a multiple of the workgroup's column span); M = B * H * Wimg
     float act_a, act_b, t_scale, t_b4, n_b1a, n_b1b, n_b2a, n_b2b;
 #ifdef VQAE_WINO_TRACE
     unsigned long long* trace;           // [wg][4 waves][32] s_memtime stamps (developer build only)
@@ -62,7 +62,7 @@ struct WinoK {
 constexpr int BPF = 6;                   // weight-fragment prefetch distance (k-slices)
 
 template <int C> struct WinoCfg {
-    static constexpr int W = C == 128 ? 32 : (C == 64 ? 64 : 128);   // grid width this channel count runs at
+    static constexpr int W = C == 128 ? 32 : (C == 64 ? 64 : 128);   // columns a workgroup spans (the image may be k times wider)
     static constexpr int PX = 4 * W;                   // output pixels per workgroup (4 image rows)
     static constexpr int TILES = PX / 4;               // 2x2 output tiles per workgroup
     static constexpr int TC = W / 2;                   // tile columns
@@ -87,7 +87,8 @@ __device__ __forceinline__ int frag_offset(int n, int k, int c, int sk = 8) {   
 // DT: autocast rounding points compiled in (16-bit modes, C = 32 only: every conv operand and conv output is rounded
 // to bf16 / f16, the arithmetic stays fp32 -- conv(x16, w16) accumulated in fp32 is what torch.autocast computes, and its
 // Winograd form differs from the direct one by fp32 rounding only).
-template <int C, int TAIL, int DT>
+// WIDE: the grid is k > 1 workgroup spans wide (column blocks); the exact-width case keeps all geometry compile-time.
+template <int C, int TAIL, int DT, bool WIDE>
 __global__ __launch_bounds__(256, 2)
 void wino_trunk_kernel(const WinoK p) {
     using K = WinoCfg<C>;
@@ -120,10 +121,15 @@ void wino_trunk_kernel(const WinoK p) {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         tile_m = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int m0 = tile_m * PX;
-    const int hw = p.H * W;
-    const int img = m0 / hw;
-    const int row0 = (m0 - img * hw) / W;                            // first image row of this workgroup (multiple of 4)
+    // tile -> (image, group of 4 rows, block of W columns); column blocks of a row group are neighbours in the order
+    const int Wimg = WIDE ? p.Wimg : W;
+    const int cblocks = WIDE ? p.Wimg / W : 1;
+    const int tpi = (p.H / 4) * cblocks;
+    const int img = tile_m / tpi;
+    const int rem = tile_m - img * tpi;
+    const int row0 = 4 * (rem / cblocks);                             // first image row of this workgroup
+    const int col0 = W * (rem % cblocks);                             // first image column
+    const int hw = p.H * Wimg;
     const float* const xim = p.t1 + (int64_t)img * hw * C;
 
     // ---- transform geometry: thread -> channel group cg, tile column tj0 (+ RP for odd items), tile rows 0 / 1 -------
@@ -134,11 +140,12 @@ void wino_trunk_kernel(const WinoK p) {
     for (int s = 0; s < 2; ++s) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int c = (2 * (tj0 + RP * s) - 1 + j) & (W - 1);    // circular in x
+            int c = col0 + 2 * (tj0 + RP * s) - 1 + j;
+            c = WIDE ? (c < 0 ? c + Wimg : (c >= Wimg ? c - Wimg : c)) : (c & (W - 1));   // circular in x
             coff[s][j] = c * C + 4 * cg;
             int r = row0 + 2 * s - 1 + j;                            // tile row s: input rows row0 + 2s - 1 .. + 2
             r = r < 0 ? r + p.H : (r >= p.H ? r - p.H : r);          // circular in y
-            roff[s][j] = r * W * C;
+            roff[s][j] = r * Wimg * C;
         }
     }
 
@@ -178,7 +185,11 @@ void wino_trunk_kernel(const WinoK p) {
     // issued behind a slow one waits for it: the residual rows (HBM) go out after the last weight-fragment load of
     // the main phase, the first weight fragments of each tail GEMM before the stores of the epilogue in front of it.
     const int wm = wave / WN, wn = wave % WN;                        // tails: MI*32 pixels x NI*32 channels per wave
-    float* const xrow = p.xio + ((int64_t)m0 + tj0) * C + 4 * cg;    // row-coalesced view of the tile: + RP * i rows
+    // row-coalesced view of the tile: thread (cg, tj0) owns pixels tj0 + RP * i, i.e. row (RP * i) / W, column
+    // tj0 + (RP * i) % W of the workgroup's 4 x W block
+    // (four row pointers + immediate column offsets: the addresses cost no registers beyond these)
+    const int64_t pix0 = ((int64_t)img * p.H + row0) * Wimg + col0 + tj0;
+    float* xr[4];                                                     // set where first needed (register budget of the main phase)
     f32x4 res[16];
     f32x4 bt[2][4][NI];
     auto tail_prefetch = [&](const float* __restrict__ wsrc) {
@@ -237,7 +248,9 @@ void wino_trunk_kernel(const WinoK p) {
                 if (xi == 3 && s == STEPS - BPF) {                     // main phase has no more loads to issue
                     tail_prefetch(p.w3);
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) res[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xrow + (int64_t)(RP * i) * C));
+                    for (int r = 0; r < 4; ++r) xr[r] = p.xio + (pix0 + (int64_t)r * Wimg) * C + 4 * cg;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) res[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr[(RP * i) / W] + ((RP * i) % W) * C));
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -364,7 +377,7 @@ void wino_trunk_kernel(const WinoK p) {
         t = t * p.t_scale;
         t = t + p.t_b4;
         t = t + res[i];
-        __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(xrow + (int64_t)(RP * i) * C));
+        __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(xr[(RP * i) / W] + ((RP * i) % W) * C));
         if (TAIL == 2) {                                              // next block's conv1 pre-op, back into T in place
 #pragma unroll
             for (int e = 0; e < 4; ++e) t[e] = rnd(elu_act(t[e] + p.n_b1a) + p.n_b1b);   // next conv1 input cast
@@ -381,13 +394,15 @@ void wino_trunk_kernel(const WinoK p) {
         acc_to_lds();
         __syncthreads();
         STAMP(12);
-        float* const yrow = p.y2 + ((int64_t)m0 + tj0) * C + 4 * cg;
+        float* yr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) yr[r] = p.y2 + (pix0 + (int64_t)r * Wimg) * C + 4 * cg;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             f32x4 t = *reinterpret_cast<const f32x4*>(trow + RP * i * LDT);
 #pragma unroll
             for (int e = 0; e < 4; ++e) t[e] = elu_act(rnd(t[e]) + p.n_b2a) + p.n_b2b;   // next conv1 output cast
-            __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(yrow + (int64_t)(RP * i) * C));
+            __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(yr[(RP * i) / W] + ((RP * i) % W) * C));
         }
         STAMP(13);
     }
@@ -427,36 +442,41 @@ __global__ void frag_weight_kernel(const float* __restrict__ w, int c, int sk, f
     out[frag_offset(i / c, i % c, c, sk)] = w[i];
 }
 
-template <int C, int DT = VQAE_DT_F32>
-int launch_wino(const WinoK& k, bool chain, hipStream_t stream) {
+template <int C, int DT, bool WIDE>
+int launch_wino_w(const WinoK& k, bool chain, hipStream_t stream) {
     using K = WinoCfg<C>;
     static bool attr_set = false;
     if (!attr_set) {
-        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)wino_trunk_kernel<C, 1, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES));
-        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)wino_trunk_kernel<C, 2, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES));
+        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)wino_trunk_kernel<C, 1, DT, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES));
+        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)wino_trunk_kernel<C, 2, DT, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES));
         attr_set = true;
     }
     const unsigned grid = (unsigned)(k.M / K::PX);
     // executed matrix work: 16 GEMMs of K = C per 4 output pixels (K_eff = 4 C per pixel) + the 1x1 tails
     const double flops = 2.0 * (double)k.M * C * (4.0 * C + C + (chain ? C : 0));
     vqae::ProfScope prof(C == 128 ? vqae::PROF_CONV3X3_TRUNK : vqae::PROF_NONE, stream, flops);
-    if (chain) wino_trunk_kernel<C, 2, DT><<<grid, 256, K::LDS_BYTES, stream>>>(k);
-    else wino_trunk_kernel<C, 1, DT><<<grid, 256, K::LDS_BYTES, stream>>>(k);
+    if (chain) wino_trunk_kernel<C, 2, DT, WIDE><<<grid, 256, K::LDS_BYTES, stream>>>(k);
+    else wino_trunk_kernel<C, 1, DT, WIDE><<<grid, 256, K::LDS_BYTES, stream>>>(k);
     prof.done();
     VQAE_LAUNCH_CHECK();
     return VQAE_OK;
+}
+
+template <int C, int DT = VQAE_DT_F32>
+int launch_wino(const WinoK& k, bool chain, hipStream_t stream) {
+    return k.Wimg == WinoCfg<C>::W ? launch_wino_w<C, DT, false>(k, chain, stream) : launch_wino_w<C, DT, true>(k, chain, stream);
 }
 
 }  // namespace
 
 namespace vqae {
 
-// fp32: (C, grid width) in {(128, 32), (64, 64), (32, 128)}; 16-bit autocast modes: (32, 128) only (the wider levels have a
-// 16-bit MFMA kernel with fused tails, conv_mfma.hip)
+// fp32: C in {128, 64, 32} on a grid whose width is a multiple of the workgroup's column span (32, 64, 128); 16-bit autocast
+// modes: C = 32 only (the wider levels have a 16-bit MFMA kernel with fused tails, conv_mfma.hip)
 bool wino_trunk_supported(int c, int h, int w, int dtype) {
-    const bool shape = dtype == VQAE_DT_F32 ? ((c == 128 && w == 32) || (c == 64 && w == 64) || (c == 32 && w == 128))
-                                            : (c == 32 && w == 128);
-    return shape && h >= 4 && h % 4 == 0;
+    const int span = c == 128 ? 32 : (c == 64 ? 64 : (c == 32 ? 128 : 0));
+    if (span == 0 || (dtype != VQAE_DT_F32 && c != 32)) return false;
+    return w >= span && w % span == 0 && h >= 4 && h % 4 == 0;
 }
 
 size_t wino_weight_floats(int c) { return (size_t)16 * c * c; }
@@ -488,7 +508,7 @@ int wino_trunk_tail(const float* t1, const float* U, const float* w3, float act_
     WinoK k;
     memset(&k, 0, sizeof(k));
     k.t1 = t1; k.U = U; k.w3 = w3; k.w1n = w1n; k.xio = xio; k.y2 = t1_next;
-    k.H = h; k.M = (int)M;
+    k.H = h; k.Wimg = w; k.M = (int)M;
     k.act_a = act_a; k.act_b = act_b; k.t_scale = t_scale; k.t_b4 = t_b4;
     k.n_b1a = n_b1a; k.n_b1b = n_b1b; k.n_b2a = n_b2a; k.n_b2b = n_b2b;
 #ifdef VQAE_WINO_TRACE

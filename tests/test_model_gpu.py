@@ -177,7 +177,9 @@ def test_winograd_trunk_equals_direct(amd, oracle, monkeypatch):
     wino = amd.NativeVQAE(amd.SPECS["B"], p)
     monkeypatch.setenv("VQAE_NO_WINOGRAD", "1")
     direct = amd.NativeVQAE(amd.SPECS["B"], p)
-    for (B, H, W) in ((2, 256, 256), (3, 128, 256), (1, 512, 256), (5, 32, 256)):     # last: a 4-row code grid, all wrap
+    # (5, 32, 256): a 4-row code grid, all wrap; (1, 256, 512) / (2, 512, 512): grids twice as wide as a workgroup's
+    # column span (two column blocks per row group)
+    for (B, H, W) in ((2, 256, 256), (3, 128, 256), (1, 512, 256), (5, 32, 256), (1, 256, 512), (2, 512, 512)):
         x = oracle.make_patches(B, 512, 11)[:, :, :H, :W].contiguous().cuda()
         z_w, z_d = wino.encode_features(x), direct.encode_features(x)
         rel = float((z_w - z_d).abs().max() / z_d.abs().max())

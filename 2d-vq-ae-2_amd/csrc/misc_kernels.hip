@@ -394,7 +394,10 @@ template <int KS>
 __global__ __launch_bounds__(256)
 void conv_small_k_kernel(const SmallK p) {
     constexpr int K = KS * KS * 8;
-    const int cg4 = p.cout >> 2;
+    __shared__ __attribute__((aligned(16))) float Wl[K * 64];          // weights [k][cout]: per-lane global weight loads made
+    const int cg4 = p.cout >> 2;                                       // this kernel run at 2.5x its HBM time
+    for (int j = threadIdx.x; j < K * p.cout; j += 256) Wl[j] = p.w[(int64_t)(j % p.cout) * K + j / p.cout];
+    __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= p.M * cg4) return;
     const int cg = (int)(i % cg4);
@@ -420,13 +423,16 @@ void conv_small_k_kernel(const SmallK p) {
         }
         v[k] = vqae::round_dt(v[k], p.dt);
     }
-    float out[4];
+    float out[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float4 wv = *reinterpret_cast<const float4*>(Wl + k * p.cout + 4 * cg);
+        out[0] = __builtin_fmaf(v[k], wv.x, out[0]); out[1] = __builtin_fmaf(v[k], wv.y, out[1]);
+        out[2] = __builtin_fmaf(v[k], wv.z, out[2]); out[3] = __builtin_fmaf(v[k], wv.w, out[3]);
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const float* wr = p.w + (int64_t)(4 * cg + e) * K;
-        float acc = 0.f;
-#pragma unroll
-        for (int k = 0; k < K; ++k) acc = __builtin_fmaf(v[k], wr[k], acc);
+        float acc = out[e];
         if (p.bias_vec) acc = acc + p.bias_vec[4 * cg + e];
         acc = vqae::round_dt(acc, p.dt);
         if (p.has_scale) { acc = acc * p.scale; acc = acc + p.bias_s; }

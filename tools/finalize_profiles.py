@@ -15,7 +15,7 @@ def per_launch(name, match):
         out[c] = sum(big) / len(big)
     return out
 
-m = lambda k: 'wino_trunk_kernel<128, 2, 0>' in k
+m = lambda k: 'wino_trunk_kernel<128, 2, 0, false>' in k
 f, w, b = per_launch('fetch', m), per_launch('write', m), per_launch('busy', m)
 M = 256 * 32 * 32
 fetch, write, alg = f['FETCH_SIZE'] * 1024 * 2, w['WRITE_SIZE'] * 1024, 4 * M * 128 * 4

@@ -408,6 +408,90 @@ void wino_trunk_kernel(const WinoK p) {
     }
 }
 
+// conv1 of the block at the head of a 'same'-block chain (the others get theirs from the previous block's tail):
+//   y = ELU(conv1x1(ELU(x + pa) + pb) + aa) + ab,   C -> C channels, fp32          (conv_block.py:199-206)
+// Same machinery as the tails above: the activated input tile is staged once in LDS ([PX][C + 4], row-coalesced
+// 128-bit loads), the weights (fragment order) are the MFMA row operand, the result goes back through LDS to
+// row-coalesced 128-bit stores.  An HBM-bound launch (2 C floats per pixel); the implicit-GEMM engine ran it at
+// 2.3 TB/s because its per-workgroup setup is paid on four K steps.
+template <int C>
+__global__ __launch_bounds__(256, 2)
+void fixup_conv1_kernel(const float* __restrict__ x, const float* __restrict__ w1f, float pa, float pb, float aa, float ab,
+                        float* __restrict__ y) {
+    using K = WinoCfg<C>;
+    constexpr int PX = K::PX, KS = K::KS, C4 = K::C4, RP = K::RP, LDT = K::LDT, WN = K::WN, MI = K::MI, NI = K::NI;
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // T[PX][LDT]
+    float* const T = lds;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, hh = lane >> 5;
+    const int cg = tid % C4, p0 = tid / C4;
+    const int64_t m0 = (int64_t)blockIdx.x * PX;
+    const float* const xrow = x + (m0 + p0) * C + 4 * cg;
+    float* const trow = T + p0 * LDT + 4 * cg;
+    f32x4 v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = *reinterpret_cast<const f32x4*>(xrow + (int64_t)(RP * i) * C);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[i][e] = elu_act(v[i][e] + pa) + pb;
+        *reinterpret_cast<f32x4*>(trow + RP * i * LDT) = v[i];
+    }
+    __syncthreads();
+    const int wm = wave / WN, wn = wave % WN;
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    {
+        const float* a0 = T + (wm * MI * 32 + li) * LDT + 4 * hh;
+        const float* b0 = w1f + (wn * NI) * (KS * 256) + 4 * lane;
+        f32x4 a[2][MI], bq[2][NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) a[0][mi] = *reinterpret_cast<const f32x4*>(a0 + mi * 32 * LDT);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) bq[0][ni] = *reinterpret_cast<const f32x4*>(b0 + ni * (KS * 256));
+#pragma unroll
+        for (int u = 0; u < KS; ++u) {
+            if (u + 1 < KS) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) a[(u + 1) & 1][mi] = *reinterpret_cast<const f32x4*>(a0 + mi * 32 * LDT + 8 * (u + 1));
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) bq[(u + 1) & 1][ni] = *reinterpret_cast<const f32x4*>(b0 + ni * (KS * 256) + 256 * (u + 1));
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[u & 1][ni][r], a[u & 1][mi][r], acc[mi][ni], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                                  // every wave is done reading T
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = elu_act(acc[mi][ni][4 * g + e] + aa) + ab;
+                *reinterpret_cast<f32x4*>(T + (wm * MI * 32 + mi * 32 + li) * LDT + (wn * NI + ni) * 32 + 8 * g + 4 * hh) = o;
+            }
+    __syncthreads();
+    float* const yrow = y + (m0 + p0) * C + 4 * cg;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        *reinterpret_cast<f32x4*>(yrow + (int64_t)(RP * i) * C) = *reinterpret_cast<const f32x4*>(trow + RP * i * LDT);
+}
+
 // U[xi*4 + nu] = (G g G^T)[xi][nu] for g = w[n][k][3][3];  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
 __global__ void wino_weight_kernel(const float* __restrict__ w, int c, int dt, float* __restrict__ U) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;              // over n * c + k
@@ -486,6 +570,39 @@ int wino_transform_weight(const float* w_oihw_dev, int c, int dtype, float* U_de
     wino_weight_kernel<<<(unsigned)ceil_div(c * c, 256), 256, 0, stream>>>(w_oihw_dev, c, dtype, U_dev);
     VQAE_LAUNCH_CHECK();
     return VQAE_OK;
+}
+
+// chain-head conv1 (fixup_conv1_kernel): fp32, C in {128, 64, 32}, M a multiple of the kernel's pixel tile
+bool fixup_conv1_supported(int c, int64_t m) {
+    if (c != 128 && c != 64 && c != 32) return false;
+    const int px = c == 128 ? 128 : (c == 64 ? 256 : 512);
+    return m > 0 && m % px == 0;
+}
+
+template <int C>
+static int launch_conv1(const float* x, const float* w1f, float pa, float pb, float aa, float ab, float* y, int64_t m,
+                        hipStream_t stream) {
+    using K = WinoCfg<C>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)fixup_conv1_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES));
+        attr_set = true;
+    }
+    ProfScope prof(C == 128 ? PROF_CONV1X1_TRUNK : PROF_NONE, stream, 2.0 * (double)m * C * C);
+    fixup_conv1_kernel<C><<<(unsigned)(m / K::PX), 256, K::LDS_BYTES, stream>>>(x, w1f, pa, pb, aa, ab, y);
+    prof.done();
+    VQAE_LAUNCH_CHECK();
+    return VQAE_OK;
+}
+
+int fixup_conv1(const float* x, const float* w1f, float pa, float pb, float aa, float ab, float* y, int64_t m, int c,
+                hipStream_t stream) {
+    VQAE_REQUIRE(x && w1f && y, VQAE_ERR_INVALID, "fixup_conv1: null pointer");
+    VQAE_REQUIRE(fixup_conv1_supported(c, m), VQAE_ERR_UNSUPPORTED, "fixup_conv1: C = %d, M = %lld", c, (long long)m);
+    VQAE_REQUIRE(m / 128 < (1ll << 31), VQAE_ERR_UNSUPPORTED, "fixup_conv1: too many pixels");
+    if (c == 128) return launch_conv1<128>(x, w1f, pa, pb, aa, ab, y, m, stream);
+    if (c == 64) return launch_conv1<64>(x, w1f, pa, pb, aa, ab, y, m, stream);
+    return launch_conv1<32>(x, w1f, pa, pb, aa, ab, y, m, stream);
 }
 
 // packed [c][c] 1x1 weights (device) -> fragment order (device); sk = 8 (fp32 MFMA k-slice) or 16 (16-bit MFMA)

@@ -29,6 +29,9 @@ int conv_tail_kslice(int dtype, int cin);
 int wino_trunk_tail(const float* t1, const float* U, const float* w3, float act_a, float act_b, float t_scale, float t_b4,
                     float* xio, const float* w1n, float n_b1a, float n_b1b, float n_b2a, float n_b2b, float* t1_next,
                     int batch, int h, int w, int c, int dtype, hipStream_t stream);
+bool fixup_conv1_supported(int c, int64_t m);
+int fixup_conv1(const float* x, const float* w1f, float pa, float pb, float aa, float ab, float* y, int64_t m, int c,
+                hipStream_t stream);
 bool down_block_supported(int cin, int h, int w);
 int frag_weight_rect(const float* w_packed_dev, int n_rows, int K, float* out_dev, hipStream_t stream);
 int down_block(const float* x, const float* w1f, const float* w2f, const float* w3f, const float* wskf, int B, int H, int W,
@@ -403,9 +406,14 @@ int run_block(vqae_handle* h, const Block& b, const Block* next, int B, int& H, 
         // trunk: conv1 (unless the previous block's tail already produced t1 in P), then ONE launch for
         // conv2 + conv3 (+ the next block's conv1 when it is another 'same' block of this width)
         if (!h->t1_ready) {
-            ConvCall c1(B, H, W, b.cin, b.br, 1, 1, 0, VQAE_PAD_NONE);
-            c1.pre(VQAE_PRE_BIAS_ELU_BIAS, b.b1a, b.b1b).act(b.b2a, b.b2b);
-            if ((rc = vqae_conv2d_f32(&c1.a, X, b.w1, nullptr, nullptr, P, st))) return rc;
+            const int64_t M = (int64_t)B * H * W;
+            if (wino && g_dt == VQAE_DT_F32 && vqae::fixup_conv1_supported(b.cin, M)) {
+                if ((rc = vqae::fixup_conv1(X, b.w1f, b.b1a, b.b1b, b.b2a, b.b2b, P, M, b.cin, st))) return rc;
+            } else {
+                ConvCall c1(B, H, W, b.cin, b.br, 1, 1, 0, VQAE_PAD_NONE);
+                c1.pre(VQAE_PRE_BIAS_ELU_BIAS, b.b1a, b.b1b).act(b.b2a, b.b2b);
+                if ((rc = vqae_conv2d_f32(&c1.a, X, b.w1, nullptr, nullptr, P, st))) return rc;
+            }
         }
         const bool chain = next && next->mode == MODE_SAME && next->cin == b.cin && next->cout == b.cin && (!wino || next->w1f);
         if (wino) {

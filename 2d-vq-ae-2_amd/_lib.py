@@ -108,6 +108,9 @@ SYMBOLS = {
     "vqae_decode_indices": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vqae_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
                              c_void_p]),
+    "vqae_block_count": (c_int, [c_void_p, c_int]),
+    "vqae_run_blocks": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, POINTER(c_int),
+                                POINTER(c_int), c_void_p]),
     "vqae_flops_per_patch": (c_double, [c_void_p, c_int, c_int, c_int, c_int]),
     "vqae_prof_begin": (c_int, [c_int, c_int]),
     "vqae_prof_end": (c_int, [POINTER(c_double), POINTER(c_int), POINTER(c_double)]),

@@ -538,8 +538,7 @@ size_t max_floats_per_patch(const vqae_handle* h, int in_h, int in_w) {
     return full > lat ? full : lat;
 }
 
-int ensure_workspace(vqae_handle* h, int B, int in_h, int in_w) {
-    const size_t need = max_floats_per_patch(h, in_h, in_w) * (size_t)(B > 0 ? B : 1);
+int ensure_bufs(vqae_handle* h, size_t need) {
     if (need > h->buf_floats) {
         VQAE_HIP_CHECK(hipDeviceSynchronize());
         for (int i = 0; i < 4; ++i) {
@@ -552,6 +551,12 @@ int ensure_workspace(vqae_handle* h, int B, int in_h, int in_w) {
                 return vqae::fail(VQAE_ERR_NOMEM, "workspace hipMalloc of %zu bytes failed", need * sizeof(float));
         h->buf_floats = need;
     }
+    return VQAE_OK;
+}
+
+int ensure_workspace(vqae_handle* h, int B, int in_h, int in_w) {
+    int rc = ensure_bufs(h, max_floats_per_patch(h, in_h, in_w) * (size_t)(B > 0 ? B : 1));
+    if (rc) return rc;
     const int64_t rows = (int64_t)B * (in_h >> h->cfg.n_down) * (in_w >> h->cfg.n_down);
     const size_t vq_need = vqae_vq_workspace_bytes(rows, h->K, h->D);
     if (vq_need > h->vq_ws_bytes) {
@@ -882,6 +887,51 @@ extern "C" int vqae_decode_indices(vqae_handle* h, const void* idx, int idx_dtyp
         if ((rc = vqae_embed_code_f32(idx, idx_dtype, h->embed, rows, h->K, h->D, h->buf[0], st))) return rc;
     }
     return run_decoder_convs(h, B, qh, qw, layout, out, st);
+}
+
+extern "C" int vqae_block_count(const vqae_handle* h, int side) {
+    if (!h) return 0;
+    return (int)(side == 0 ? h->enc.size() : h->dec.size());
+}
+
+extern "C" int vqae_run_blocks(vqae_handle* h, int side, int first, int count, const float* x, int B, int in_h, int in_w,
+                               float* y, int* out_h, int* out_w, void* stream) {
+    if (h) g_dt = h->cfg.compute_dtype;
+    hipStream_t st = (hipStream_t)stream;
+    VQAE_REQUIRE(h && x && y, VQAE_ERR_INVALID, "vqae_run_blocks: null pointer");
+    VQAE_REQUIRE(side == 0 || side == 1, VQAE_ERR_INVALID, "vqae_run_blocks: side %d", side);
+    std::vector<Block>& v = side == 0 ? h->enc : h->dec;
+    VQAE_REQUIRE(first >= 0 && count >= 1 && (size_t)first + (size_t)count <= v.size(), VQAE_ERR_INVALID,
+                 "vqae_run_blocks: blocks [%d, %d) of %zu", first, first + count, v.size());
+    VQAE_REQUIRE(B >= 0 && in_h >= 1 && in_w >= 1, VQAE_ERR_INVALID, "vqae_run_blocks: bad shape");
+    int H = in_h, W = in_w;
+    if (B == 0) return VQAE_OK;
+    // workspace: the widest tensor any block of the range touches (an 'up' block's upsampled 2C tensor is 4x its input)
+    size_t need = 0;
+    {
+        double hh = in_h, ww = in_w;
+        for (int i = first; i < first + count; ++i) {
+            const Block& b = v[i];
+            VQAE_REQUIRE(b.mode != MODE_DOWN || (((int)hh % 2 == 0) && ((int)ww % 2 == 0)), VQAE_ERR_INVALID,
+                         "vqae_run_blocks: odd input size at a 'down' block");
+            const size_t wide = (size_t)std::max(std::max(b.cin, b.cout), b.br) * (b.mode == MODE_UP ? 4 : 1);
+            need = std::max(need, (size_t)B * (size_t)hh * (size_t)ww * wide);
+            if (b.mode == MODE_DOWN) { hh /= 2; ww /= 2; } else if (b.mode == MODE_UP) { hh *= 2; ww *= 2; }
+        }
+    }
+    int rc;
+    if ((rc = ensure_bufs(h, need))) return rc;
+    if (h->cfg.block_kind == VQAE_BLOCK_MBCONV)
+        return vqae::fail(VQAE_ERR_UNSUPPORTED, "vqae_run_blocks: Fixup blocks only");
+    VQAE_HIP_CHECK(hipMemcpyAsync(h->buf[0], x, (size_t)B * in_h * in_w * v[first].cin * 4, hipMemcpyDeviceToDevice, st));
+    h->t1_ready = false;
+    for (int i = first; i < first + count; ++i)
+        if ((rc = run_block(h, v[i], i + 1 < first + count ? &v[i + 1] : nullptr, B, H, W, st))) return rc;
+    h->t1_ready = false;
+    VQAE_HIP_CHECK(hipMemcpyAsync(y, h->buf[0], (size_t)B * H * W * v[first + count - 1].cout * 4, hipMemcpyDeviceToDevice, st));
+    if (out_h) *out_h = H;
+    if (out_w) *out_w = W;
+    return VQAE_OK;
 }
 
 extern "C" int vqae_forward(vqae_handle* h, const float* x, int B, int in_h, int in_w, int layout, float* out, void* idx,

@@ -147,6 +147,31 @@ class NativeVQAE:
                                      ops.idx_code(idx_dtype), ops._p(loss), ops._stream()))
         return out, idx, loss
 
+    def block_count(self, side):
+        return int(L.lib().vqae_block_count(self._h, 0 if side in (0, "encoder") else 1))
+
+    def run_blocks(self, side, first, count, x_nhwc):
+        """Blocks [first, first + count) of the encoder ('encoder' / 0) or decoder ('decoder' / 1) block list on
+        x [B,H,W,cin] (NHWC) through the handle's own kernel dispatch -> y [B,H',W',cout] (NHWC).  The block
+        order is spec.encoder_block_names / decoder_block_names."""
+        from .spec import decoder_block_names, encoder_block_names
+        ops._need_gpu(x_nhwc)
+        x = x_nhwc.contiguous().float()
+        B, H, W, cin = x.shape
+        s = 0 if side in (0, "encoder") else 1
+        names = encoder_block_names(self.spec) if s == 0 else decoder_block_names(self.spec)
+        assert 0 <= first and count >= 1 and first + count <= len(names), (first, count, len(names))
+        assert cin == names[first][2], f"block {names[first][0]} takes {names[first][2]} channels, got {cin}"
+        Ho, Wo = H, W
+        for _, mode, _, _ in names[first:first + count]:
+            Ho, Wo = (Ho // 2, Wo // 2) if mode == "down" else ((2 * Ho, 2 * Wo) if mode == "up" else (Ho, Wo))
+        y = torch.empty((B, Ho, Wo, names[first + count - 1][3]), dtype=torch.float32, device=x.device)
+        oh, ow = ctypes.c_int(0), ctypes.c_int(0)
+        L.check(L.lib().vqae_run_blocks(self._h, s, first, count, ops._p(x), B, H, W, ops._p(y), ctypes.byref(oh),
+                                        ctypes.byref(ow), ops._stream()))
+        assert B == 0 or (oh.value, ow.value) == (Ho, Wo)
+        return y
+
     def flops_per_patch(self, h, w, encoder=True, decoder=True):
         return float(L.lib().vqae_flops_per_patch(self._h, h, w, int(encoder), int(decoder)))
 

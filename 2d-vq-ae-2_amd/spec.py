@@ -39,6 +39,10 @@ SPECS = {
     "A": VQAESpec(stem=8, n_down=4, n_enc=50, num_embeddings=256, projection_dim=8),     # reference default, 512^2
     "B": VQAESpec(stem=16, n_down=3, n_enc=50, num_embeddings=256, projection_dim=0),    # BASELINE configs 1-2, 256^2
     "C": VQAESpec(stem=32, n_down=3, n_enc=50, num_embeddings=1024, projection_dim=0),   # BASELINE config 4
+    # mid-size models that reach the production kernels of A/B/C on 128x128 inputs (per-block parity taps)
+    "mid": VQAESpec(stem=32, n_down=2, n_pre=1, n_post=4, n_enc=3, num_embeddings=64, projection_dim=0),
+    "mid16": VQAESpec(stem=16, n_down=2, n_pre=1, n_post=2, n_enc=2, num_embeddings=32, projection_dim=0),
+    "midA": VQAESpec(stem=8, n_down=3, n_pre=1, n_post=2, n_enc=2, num_embeddings=64, projection_dim=8),
     "tiny": VQAESpec(stem=8, n_down=2, n_pre=1, n_post=1, n_enc=2, num_embeddings=16, projection_dim=0),
     "tinyP": VQAESpec(stem=8, n_down=2, n_pre=1, n_post=1, n_enc=2, num_embeddings=32, projection_dim=8),
     # MBConv / EfficientNetV2 variant

@@ -264,6 +264,18 @@ int vqae_decode_indices(vqae_handle* h, const void* idx_dev, int idx_dtype, int 
 int vqae_forward(vqae_handle* h, const float* x_dev, int batch, int in_h, int in_w, int layout, float* out_dev,
                  void* idx_dev, int idx_dtype, float* loss_dev, void* stream);
 
+/* Sub-module calls.  The reference lets a caller run any part of the block stacks on its own
+ * (`model.encoder.down_layers[0].layers[l].layers[b](x)`, `model.encoder.pre_enc_layers[0][i:j](x)` --
+ * nn.ModuleList / nn.Sequential of PreActFixupResBlock, vq_ae/model.py:160-176,249-264, conv_block.py:196-216).
+ * vqae_run_blocks runs residual blocks [first, first + count) of the encoder block list (side 0: the DownBlock
+ * levels in order, then pre_enc; model.py:199-208) or of the decoder list (side 1: post_enc, then the UpBlock
+ * levels; model.py:278-289) on x_dev [B][in_h][in_w][cin of block `first`] (NHWC fp32) through exactly the kernels
+ * the handle-level calls dispatch (including the cross-block fusions when count > 1), and writes
+ * y_dev [B][*out_h][*out_w][cout of the last block].  The per-block parity tests are built on it. */
+int vqae_block_count(const vqae_handle* h, int side);
+int vqae_run_blocks(vqae_handle* h, int side, int first, int count, const float* x_dev, int batch, int in_h, int in_w,
+                    float* y_dev, int* out_h, int* out_w, void* stream);
+
 /* Introspection for benchmarks: algorithmic FLOPs (2*MACs) of the conv stacks per patch. */
 double vqae_flops_per_patch(const vqae_handle* h, int in_h, int in_w, int encoder, int decoder);
 

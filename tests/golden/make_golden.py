@@ -175,6 +175,51 @@ def gen_model_autocast(name, batch, size, dtype, tag):
          q_sample=q.float()[:, ::8, ::4, ::4].numpy(), embed=p["encoder.vq_layers.0.embed"].numpy())
 
 
+# ---------------------------------------------------------------- G9: per-block taps of the mid-size models
+def tap_sample(t):
+    """Strided sample of an activation tap [B,C,H,W]: channels ::4 (::2 below 16), 8x8 spatial positions (phase 1 so
+    interior pixels are sampled, not only tile corners)."""
+    cs = 4 if t.shape[1] >= 16 else 2
+    s = max(1, t.shape[2] // 8)
+    return t[:, ::cs, 1::s, 1::s]
+
+
+def gen_model_taps(name, batch, size, dtype, tag):
+    """The reference run block by block (fp32, or under torch.autocast('cpu', dtype) as in
+    extract_embeddings.py:124-125) on a model whose levels reach the production kernels; records a strided sample
+    and the exact fp64 sum / sum of squares of EVERY block output.  The oracle must reproduce all of them bit for
+    bit; the GPU tests then compare each HIP block against the oracle's full tensors (tests/test_blocks_gpu.py)."""
+    import contextlib
+    spec = O.SPECS[name]
+    p = O.make_params(spec, 0)
+    x = O.make_patches(batch, size, 0)
+    p = O.calibrate_codebook(O.make_patches(2, size, 99), p, spec)
+    model = S.build_reference_model(spec, p)
+    ctx = (lambda: torch.autocast("cpu", dtype=dtype)) if dtype is not None else contextlib.nullcontext
+    with ctx():
+        rt = ref_forward_with_taps(model, x)
+        out, _ = model(x)
+    assert torch.equal(rt["out"], out)
+    ot = {}
+    oout, olosses = O.vqae_forward(x, p, spec, ot, dtype=dtype)
+    assert torch.equal(oout, out) and torch.equal(ot["idx"], rt["idx"])
+    arrays = dict(spec=np.array(repr(spec.to_dict())), batch=batch, size=size, tag=np.array(tag),
+                  idx=rt["idx"].numpy().astype(np.uint16), loss=np.float32(float(rt["loss"])),
+                  embed=p["encoder.vq_layers.0.embed"].numpy())
+    n = 0
+    for k, v in rt.items():
+        if k in ("idx", "loss"):
+            continue
+        v = v.float()
+        assert torch.equal(ot[k].float(), v) if k in ot else True, k       # oracle == reference on the FULL tensor
+        arrays["tap:" + k] = tap_sample(v).numpy()
+        arrays["sum:" + k] = np.array([v.double().sum().item(), (v.double() ** 2).sum().item()])
+        n += 1
+    print(f"  {name} {tag}: {n} taps, oracle identical on every full tensor; codes used "
+          f"{rt['idx'].unique().numel()}/{spec.num_embeddings}")
+    save(f"taps_{name}_{tag}", **arrays)
+
+
 # ---------------------------------------------------------------- G5: driver
 def gen_driver():
     S.install()
@@ -278,7 +323,7 @@ def gen_ema():
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="vq,tiny,tinyP,B,A,C,driver,ema,autocast,mbconv")
+    ap.add_argument("--only", default="vq,tiny,tinyP,B,A,C,driver,ema,autocast,mbconv,taps")
     args = ap.parse_args()
     todo = args.only.split(",")
     torch.manual_seed(0)
@@ -305,6 +350,12 @@ if __name__ == "__main__":
         print("G8 MBConv / EfficientNetV2 variant")
         gen_model("tinyM", 2, 32, True)
         gen_model("BM", 2, 256, False)
+    if "taps" in todo:
+        print("G9 per-block taps (mid-size models reaching the production kernels)")
+        for nm in ("mid", "mid16", "midA"):
+            gen_model_taps(nm, 2, 128, None, "f32")
+            gen_model_taps(nm, 2, 128, torch.bfloat16, "bf16")
+            gen_model_taps(nm, 2, 128, torch.float16, "f16")
     if "driver" in todo:
         print("G5 driver"); gen_driver()
     if "ema" in todo:

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import load_golden, tap_sample
 
 
 @pytest.mark.parametrize("D,K", [(8, 256), (128, 256), (256, 1024), (32, 16)])
@@ -57,6 +57,37 @@ def test_model_taps_match_reference_fixture(oracle, name):
         if k.startswith("tap:") and k[4:] in taps:
             assert np.array_equal(taps[k[4:]].numpy(), g[k]), k
     assert np.array_equal(out.numpy(), g["tap:out"])
+
+
+TDT = {"f32": None, "bf16": torch.bfloat16, "f16": torch.float16}
+
+
+@pytest.mark.parametrize("tag", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("name", ["mid", "mid16", "midA"])
+def test_block_taps_match_reference_fixture(oracle, name, tag):
+    """Mid-size models (levels that reach the production kernels of cfg A/B/C): every block output of the oracle
+    equals the reference's recorded one -- strided sample bit for bit, full tensor through its fp64 sum and sum of
+    squares -- in fp32 and under CPU autocast bf16 / f16 (extract_embeddings.py:124-125)."""
+    g = load_golden(f"taps_{name}_{tag}")
+    spec = oracle.SPECS[name]
+    assert ast.literal_eval(str(g["spec"])) == spec.to_dict()
+    p = oracle.make_params(spec, 0)
+    p["encoder.vq_layers.0.embed"] = torch.from_numpy(g["embed"])
+    x = oracle.make_patches(int(g["batch"]), int(g["size"]), 0)
+    taps = {}
+    out, losses = oracle.vqae_forward(x, p, spec, taps, dtype=TDT[tag])
+    taps["out"] = out
+    assert np.array_equal(taps["idx"].numpy(), g["idx"].astype(np.int64))
+    n = 0
+    for k in g.files:
+        if not k.startswith("tap:"):
+            continue
+        t = taps[k[4:]].float()
+        assert np.array_equal(tap_sample(t).numpy(), g[k]), k
+        s1, s2 = g["sum:" + k[4:]]
+        assert t.double().sum().item() == s1 and (t.double() ** 2).sum().item() == s2, k
+        n += 1
+    assert n == len(oracle.encoder_blocks(spec)) + len(oracle.decoder_blocks(spec)) + 4   # + stem, z, q, out
 
 
 def test_model_B_matches_reference_fixture(oracle):

@@ -29,6 +29,13 @@ int conv_tail_kslice(int dtype, int cin);
 int wino_trunk_tail(const float* t1, const float* U, const float* w3, float act_a, float act_b, float t_scale, float t_b4,
                     float* xio, const float* w1n, float n_b1a, float n_b1b, float n_b2a, float n_b2b, float* t1_next,
                     int batch, int h, int w, int c, int dtype, hipStream_t stream);
+bool trunk16_supported(int c, int h, int w, int dtype);
+size_t trunk16_weight_bytes(int c, int taps);
+int trunk16_pack_weight(const float* w_packed_dev, int c, int taps, int dtype, void* out_dev, hipStream_t stream);
+int trunk16_round_pack(const float* src, void* dst, int64_t n, int dtype, hipStream_t stream);
+int trunk16_block(const void* t1, const void* w2f, const void* w3f, float act_a, float act_b, float t_scale, float t_b4,
+                  float* xio, const void* w1nf, float n_b1a, float n_b1b, float n_b2a, float n_b2b, void* t1_next,
+                  int batch, int h, int w, int c, int dtype, hipStream_t stream);
 bool fixup_conv1_supported(int c, int64_t m);
 int fixup_conv1(const float* x, const float* w1f, float pa, float pb, float aa, float ab, float* y, int64_t m, int c,
                 hipStream_t stream);
@@ -101,6 +108,7 @@ struct Block {
     float* wU = nullptr;                  // Winograd-domain conv2 weights [16][C][C] (fp32 trunk blocks, C = 64 / 128, conv_wino.hip)
     float *w1f = nullptr, *w3f = nullptr; // conv1 / conv3 weights in MFMA fragment order for the fused tails (both trunk kernels)
     float *w2f = nullptr, *wskf = nullptr;// 'down' blocks: conv2 / skip_conv in fragment order too (down_fused.hip)
+    void *w1h = nullptr, *w2h = nullptr, *w3h = nullptr;   // 16-bit modes: conv1 / conv2 / conv3 as 16-bit MFMA fragments (trunk16.hip)
     // MBConv (conv_block.py:240-321), BatchNorms folded: br = expanded width, w2 = depthwise taps [k*k][br]
     int kind = VQAE_BLOCK_FIXUP, hidden = 0;
     float *bv1 = nullptr, *bv2 = nullptr, *bv3 = nullptr;                        // folded BN shifts
@@ -241,6 +249,15 @@ int load_block(vqae_handle* h, const TensorMap& tm, const std::string& pre, int 
         if ((rc = dev_alloc(h, (size_t)cin * cin * 4, &f1)) || (rc = dev_alloc(h, (size_t)cin * cin * 4, &f3))) return rc;
         b->w1f = (float*)f1; b->w3f = (float*)f3;
         if ((rc = vqae::wino_frag_weight(b->w1, cin, sk, b->w1f, nullptr)) || (rc = vqae::wino_frag_weight(b->w3, cin, sk, b->w3f, nullptr))) return rc;
+        VQAE_HIP_CHECK(hipDeviceSynchronize());
+    }
+    b->w1h = b->w2h = b->w3h = nullptr;
+    if (mode == MODE_SAME && cout == cin && h->cfg.compute_dtype != VQAE_DT_F32 && (cin == 64 || cin == 128 || cin == 256)) {
+        struct { float* src; int taps; void** dst; } m[3] = {{b->w1, 1, &b->w1h}, {b->w2, 9, &b->w2h}, {b->w3, 1, &b->w3h}};
+        for (auto& e : m) {
+            if ((rc = dev_alloc(h, vqae::trunk16_weight_bytes(cin, e.taps), e.dst))) return rc;
+            if ((rc = vqae::trunk16_pack_weight(e.src, cin, e.taps, h->cfg.compute_dtype, *e.dst, nullptr))) return rc;
+        }
         VQAE_HIP_CHECK(hipDeviceSynchronize());
     }
     if (mode != MODE_SAME) {
@@ -401,6 +418,22 @@ int run_block(vqae_handle* h, const Block& b, const Block* next, int B, int& H, 
     if (b.kind == VQAE_BLOCK_MBCONV) return run_mbconv(h, b, B, H, W, st);
     float *X = h->buf[0], *P = h->buf[1], *Q = h->buf[2], *R = h->buf[3];
     int rc;
+    if (b.mode == MODE_SAME && b.w2h && h->fuse_trunk && vqae::trunk16_supported(b.cin, H, W, g_dt)) {
+        // 16-bit modes, C = 64 / 128 / 256 (trunk16.hip): t1 travels as 16-bit; one launch per block
+        if (!h->t1_ready) {                          // chain head: conv1 by the generic kernel (fp32 out), then the conv2 input cast
+            ConvCall c1(B, H, W, b.cin, b.br, 1, 1, 0, VQAE_PAD_NONE);
+            c1.pre(VQAE_PRE_BIAS_ELU_BIAS, b.b1a, b.b1b).act(b.b2a, b.b2b);
+            if ((rc = vqae_conv2d_f32(&c1.a, X, b.w1, nullptr, nullptr, Q, st))) return rc;
+            if ((rc = vqae::trunk16_round_pack(Q, P, (int64_t)B * H * W * b.cin, g_dt, st))) return rc;
+        }
+        const bool chain = next && next->mode == MODE_SAME && next->cin == b.cin && next->cout == b.cin && next->w1h;
+        if ((rc = vqae::trunk16_block(P, b.w2h, b.w3h, b.b3a, b.b3b, b.scale, b.b4, X, chain ? next->w1h : nullptr,
+                                      chain ? next->b1a : 0.f, chain ? next->b1b : 0.f, chain ? next->b2a : 0.f,
+                                      chain ? next->b2b : 0.f, chain ? Q : nullptr, B, H, W, b.cin, g_dt, st))) return rc;
+        if (chain) std::swap(h->buf[1], h->buf[2]);
+        h->t1_ready = chain;
+        return VQAE_OK;
+    }
     const bool wino = b.mode == MODE_SAME && b.wU && h->fuse_trunk && vqae::wino_trunk_supported(b.cin, H, W, g_dt);
     if (b.mode == MODE_SAME && (wino || ((b.cin == 128 || b.cin == 64) && b.cout == b.cin && h->fuse_trunk))) {
         // trunk: conv1 (unless the previous block's tail already produced t1 in P), then ONE launch for

@@ -1,0 +1,379 @@
+// 16-bit-native trunk Fixup block (torch.autocast semantics, BASELINE configs #3 bf16 / #4 fp16): one launch runs
+//   conv2 (3x3 circular, conv_block.py:203) -> ELU -> conv3 (1x1) -> * scale + bias4 + residual (conv_block.py:204-214)
+//   [-> the NEXT block's bias / ELU / conv1 (1x1) / ELU (conv_block.py:199-202)]
+// on v_mfma_f32_32x32x16_{bf16,f16}, for 'same' blocks with C in {64, 128, 256} channels on grids 32 / 64 / 128 wide.
+//
+// What differs from conv_mfma.hip's TAIL kernel (which this replaces in the 16-bit modes; 277 us -> see DESIGN.md):
+//   * t1 / t1_next -- the conv2 operand, i.e. values that autocast has ALREADY rounded to the 16-bit type -- live in HBM
+//     as 16-bit (half the bytes, exact); only the residual stream x stays fp32, as it does in the reference (the
+//     shape-(1,) fp32 Fixup scalars promote every elementwise op to fp32).
+//   * the block input (4 image rows + one wrap-around halo row above and below = 128 output pixels) is staged ONCE in
+//     LDS as 16-bit, [pixel][C + 8]; all nine taps read their MFMA operand from it with shifted addresses -- no per-tap
+//     re-gather from global, no conversion or ELU inside the K loop, no barrier inside the K loop.
+//   * weights are the MFMA *row* operand, streamed from L2 in fragment order ([n-tile][k-step][lane][8]: one wave-wide
+//     load = 1 KiB contiguous) through a register ring; a wave owns 32 output channels x all 128 pixels, so every
+//     weight fragment is loaded once per workgroup and feeds 4 MFMAs, and the result has the pixel on the lane and four
+//     consecutive channels per register quad: every epilogue access is 8 / 16 bytes wide.
+//
+// Rounding points are those of conv_mfma.hip (= torch.autocast): conv operands and conv outputs RNE to the 16-bit
+// type, fp32 accumulation, fp32 scalar bias / ELU / scale / residual arithmetic, no FMA contraction.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+using vqae::elu_act;
+
+template <int DT> struct E16;
+template <> struct E16<VQAE_DT_BF16> {
+    using elem = __bf16; using x8 = bf16x8; using x4 = bf16x4;
+    static __device__ __forceinline__ f32x16 mma(const x8& a, const x8& b, const f32x16& c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float rnd(float v) { return (float)(__bf16)v; }
+};
+template <> struct E16<VQAE_DT_F16> {
+    using elem = _Float16; using x8 = f16x8; using x4 = f16x4;
+    static __device__ __forceinline__ f32x16 mma(const x8& a, const x8& b, const f32x16& c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float rnd(float v) { return (float)(_Float16)v; }
+};
+
+struct T16K {
+    const void* __restrict__ t1;     // [M][C] 16-bit: round16(ELU(round16(conv1) + b2a) + b2b), the conv2 operand
+    const void* __restrict__ w2f;    // conv2 weights, fragment order [C/32][9 * C/16][64][8] 16-bit
+    const void* __restrict__ w3f;    // conv3 weights, fragment order [C/32][C/16][64][8]
+    const void* __restrict__ w1nf;   // next block's conv1, same order (NEXT)
+    float* xio;                      // [M][C] fp32 residual stream, updated in place
+    void* t1n;                       // [M][C] 16-bit: the next block's t1 (NEXT)
+    int H;                           // image rows (a multiple of the tile's row count)
+    float act_a, act_b, t_scale, t_b4, n_b1a, n_b1b, n_b2a, n_b2b;
+};
+
+template <int C, int W> struct T16Cfg {
+    static_assert(W == 32 || W == 64 || W == 128, "grid width");
+    static_assert(C == 64 || C == 128 || C == 256, "channels");
+    static constexpr int NW = C / 32;                 // waves = 32-channel output slices
+    static constexpr int NT = NW * 64;                // threads
+    static constexpr int SEG = W / 32;                // 32-pixel segments per image row
+    static constexpr int R = 4 / SEG;                 // image rows per workgroup (4 m-tiles of 32 pixels = 128 pixels)
+    static constexpr int PS = 2 * C + 16;             // LDS bytes per pixel: odd 16-B slot stride -> conflict-free b128 reads
+    static constexpr int KS = C / 16;                 // k-slices per tap
+    static constexpr int LDS_BYTES = (R + 2) * W * PS;
+};
+
+// Developer aid (off by default; tools/t16_trace.py): per-phase s_memtime stamps of every wave.
+#ifdef VQAE_T16_TRACE
+__device__ unsigned long long* g_t16_trace = nullptr;
+#define STAMP(i) do { if (lane == 0 && g_t16_trace) g_t16_trace[((int64_t)blockIdx.x * 8 + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
+constexpr int NB_MAX = 8;                             // weight-fragment ring depth (k-steps in flight per wave): 8, or 6 at C = 64
+
+template <int C, int W, int DT, bool NEXT>
+__global__ __launch_bounds__(C * 2, 2)
+void trunk16_kernel(const T16K p) {
+    using K = T16Cfg<C, W>;
+    using E = E16<DT>;
+    using x8 = typename E::x8;
+    using x4 = typename E::x4;
+    constexpr int NT = K::NT, SEG = K::SEG, R = K::R, PS = K::PS, KS = K::KS;
+    constexpr int NS2 = 9 * KS;
+    constexpr int NB = (3 * KS) % NB_MAX == 0 ? NB_MAX : 6;
+    extern __shared__ __attribute__((aligned(16))) char lds[];      // A: [(R + 2) * W pixels][PS];  T: [128 pixels][PS] over it
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // = n-tile: output channels [32 wave, 32 wave + 32)
+    const int x = lane & 31, h = lane >> 5;
+
+    // XCD-contiguous tile order: neighbouring row groups of an image (shared halo rows) meet in one L2 (speed only)
+    int tile;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tiles_per_img = p.H / R;
+    const int img = tile / tiles_per_img;
+    const int y0 = (tile - img * tiles_per_img) * R;
+    const int64_t pix0 = ((int64_t)img * p.H + y0) * W;             // first output pixel of this tile (NHWC pixel index)
+    STAMP(0);
+
+    // ---- stage the R + 2 input rows (wrap-around halo) in LDS, 16-bit, once --------------------------------------------
+    {
+        constexpr int CPP = C * 2 / 16;                             // 16-byte chunks per pixel
+        constexpr int NCH = (R + 2) * W * CPP;
+        static_assert(NCH % NT == 0, "chunks per thread");
+        constexpr int PER = NCH / NT;
+        const char* const src = (const char*)p.t1 + (int64_t)img * p.H * W * C * 2;
+        u32x4 v[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int c = tid + i * NT;
+            const int px = c / CPP, part = c % CPP;
+            const int br = px / W, col = px % W;
+            int iy = y0 - 1 + br;
+            iy = iy < 0 ? iy + p.H : (iy >= p.H ? iy - p.H : iy);
+            v[i] = *reinterpret_cast<const u32x4*>(src + ((int64_t)(iy * W + col) * C * 2 + part * 16));
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int c = tid + i * NT;
+            const int px = c / CPP, part = c % CPP;
+            *reinterpret_cast<u32x4*>(lds + px * PS + part * 16) = v[i];
+        }
+    }
+
+    // ---- conv2: acc[mi] (32 channels x 32 pixels) += W2[tap] (row operand, from L2) x A[tap-shifted pixels] (LDS) --------
+    const char* const w2p = (const char*)p.w2f + ((int64_t)wave * NS2 * 64 + lane) * 16;
+    x8 wq[NB];
+#pragma unroll
+    for (int s = 0; s < NB; ++s) wq[s] = *reinterpret_cast<const x8*>(w2p + s * 1024);
+    int abase[SEG][3];                                              // byte offset of (segment, dx)'s pixel column + lane's k half
+#pragma unroll
+    for (int sg = 0; sg < SEG; ++sg)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) abase[sg][dx] = ((sg * 32 + x + dx - 1) & (W - 1)) * PS + 16 * h;
+    f32x16 acc[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+    __syncthreads();
+    static_assert((3 * KS) % NB == 0, "ring depth must divide a tap row's k-steps");
+    // one tap row (dy) per trip of a real loop, its 3 * KS k-steps unrolled: keeps the scheduling window (and the
+    // registers the compiler spends on hoisted LDS reads) bounded.  The ring runs NB steps ahead across trips; the
+    // last trip's look-ahead reads NB KiB past this wave's fragments (the next n-tile's, or the buffer's tail pad).
+    const char* wrow = w2p;
+    const char* arow = lds;
+#pragma unroll 1
+    for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+        for (int s = 0; s < 3 * KS; ++s) {
+            const int dx = s / KS, ks = s % KS;
+            const x8 wc = wq[s % NB];
+            wq[s % NB] = *reinterpret_cast<const x8*>(wrow + (s + NB) * 1024);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int row = mi / SEG, sg = mi % SEG;
+                const x8 a = *reinterpret_cast<const x8*>(arow + abase[sg][dx] + row * W * PS + ks * 32);
+                acc[mi] = E::mma(wc, a, acc[mi]);
+            }
+        }
+        wrow += 3 * KS * 1024;
+        arow += W * PS;
+    }
+    STAMP(2);
+
+    // result layout: lane = pixel x of m-tile mi, register r = channel 32 wave + (r & 3) + 8 (r >> 2) + 4 h
+    const int cbase = wave * 32 + 4 * h;                            // + 8 q + {0..3}
+    auto to_T = [&](const f32x4& v, int mi, int q) {                // 4 consecutive channels of one pixel -> T, 16-bit
+        *reinterpret_cast<x4*>(lds + (mi * 32 + x) * PS + (cbase + 8 * q) * 2) = __builtin_convertvector(v, x4);
+    };
+    auto gemm1x1 = [&](const void* wf) {                            // acc = Wf (C x C, row operand) x T (K = C)
+        const char* const wp = (const char*)wf + ((int64_t)wave * KS * 64 + lane) * 16;
+        constexpr int NR = KS < NB ? KS : NB;
+        x8 w[NR];
+#pragma unroll
+        for (int s = 0; s < NR; ++s) w[s] = *reinterpret_cast<const x8*>(wp + s * 1024);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+        __syncthreads();                                            // T complete
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const x8 wc = w[s % NR];
+            if (s + NR < KS) w[s % NR] = *reinterpret_cast<const x8*>(wp + (s + NR) * 1024);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const x8 b = *reinterpret_cast<const x8*>(lds + (mi * 32 + x) * PS + 16 * h + s * 32);
+                acc[mi] = E::mma(wc, b, acc[mi]);
+            }
+        }
+    };
+
+    // ---- t2 = round(ELU(round(conv2) + b3a) + b3b) -> T (over the dead input rows) ------------------------------------
+    __syncthreads();                                                // every wave is done reading A
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = elu_act(E::rnd(acc[mi][4 * q + e]) + p.act_a) + p.act_b;
+            to_T(v, mi, q);                                         // the cast is the conv3 input rounding
+        }
+
+    // residual rows: requested now, consumed after conv3 (16 B per lane: 4 consecutive channels of one pixel)
+    float* const xrow = p.xio + (pix0 + x) * C + cbase;
+    f32x4 xr[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xr[mi][q] = *reinterpret_cast<const f32x4*>(xrow + (int64_t)mi * 32 * C + 8 * q);
+
+    STAMP(3);
+    gemm1x1(p.w3f);                                                 // conv3
+    STAMP(4);
+
+    // ---- out = round(conv3) * scale + bias4 + x, in place; u = round(ELU(out + b1a') + b1b') for the next conv1 --------
+    if (NEXT) __syncthreads();                                      // conv3 finished reading T
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 t, u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = E::rnd(acc[mi][4 * q + e]) * p.t_scale;
+                v = v + p.t_b4;
+                v = v + xr[mi][q][e];
+                t[e] = v;
+                u[e] = elu_act(v + p.n_b1a) + p.n_b1b;
+            }
+            *reinterpret_cast<f32x4*>(xrow + (int64_t)mi * 32 * C + 8 * q) = t;
+            if (NEXT) to_T(u, mi, q);
+        }
+    STAMP(5);
+    if constexpr (NEXT) {
+        gemm1x1(p.w1nf);                                            // the next block's conv1
+        STAMP(6);
+        typename E::elem* const trow = (typename E::elem*)p.t1n + (pix0 + x) * C + cbase;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = elu_act(E::rnd(acc[mi][4 * q + e]) + p.n_b2a) + p.n_b2b;
+                *reinterpret_cast<x4*>(trow + (int64_t)mi * 32 * C + 8 * q) = __builtin_convertvector(v, x4);
+            }
+    }
+    STAMP(7);
+}
+
+// packed fp32 [C n][taps * C] (tap-major K, vqae_conv_pack_weight_f32; already rounded to the 16-bit type) ->
+// fragment order [C/32 n-tiles][taps * C/16 k-steps][64 lanes][8]: lane (r, h) of k-step (tap, ks) holds
+// w[n = 32 nt + r][tap][k = 16 ks + 8 h + j], j = 0..7 -- the MFMA row-operand fragment of that step.
+template <typename EL>
+__global__ void pack16_kernel(const float* __restrict__ w, int c, int taps, EL* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int ks_n = c / 16;
+    if (i >= (int64_t)c * taps * c) return;
+    const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+    const int64_t st = i >> 9;
+    const int s = (int)(st % (taps * ks_n)), nt = (int)(st / (taps * ks_n));
+    const int tap = s / ks_n, ks = s % ks_n;
+    const int n = nt * 32 + (lane & 31), k = ks * 16 + 8 * (lane >> 5) + j;
+    out[i] = (EL)w[(int64_t)n * taps * c + tap * c + k];
+}
+
+template <typename EL>
+__global__ void round_pack16_kernel(const float* __restrict__ src, EL* __restrict__ dst, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 v = reinterpret_cast<const f32x4*>(src)[i];
+    typedef EL el4 __attribute__((ext_vector_type(4)));
+    reinterpret_cast<el4*>(dst)[i] = __builtin_convertvector(v, el4);
+}
+
+template <int C, int W, int DT>
+int launch_t16(const T16K& k, bool next, int n_tiles, hipStream_t stream) {
+    using K = T16Cfg<C, W>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)trunk16_kernel<C, W, DT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES));
+        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)trunk16_kernel<C, W, DT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES));
+        attr_set = true;
+    }
+    const double m = (double)n_tiles * 128.0;
+    vqae::ProfScope prof(C >= 128 && W == 32 ? vqae::PROF_CONV3X3_TRUNK : 0, stream, 2.0 * m * C * (9.0 * C + C + (next ? C : 0)));
+    if (next) trunk16_kernel<C, W, DT, true><<<n_tiles, K::NT, K::LDS_BYTES, stream>>>(k);
+    else trunk16_kernel<C, W, DT, false><<<n_tiles, K::NT, K::LDS_BYTES, stream>>>(k);
+    prof.done();
+    VQAE_LAUNCH_CHECK();
+    return VQAE_OK;
+}
+
+template <int DT>
+int launch_t16_cw(const T16K& k, bool next, int c, int w, int n_tiles, hipStream_t stream) {
+    if (c == 128 && w == 32) return launch_t16<128, 32, DT>(k, next, n_tiles, stream);
+    if (c == 256 && w == 32) return launch_t16<256, 32, DT>(k, next, n_tiles, stream);
+    if (c == 64 && w == 64) return launch_t16<64, 64, DT>(k, next, n_tiles, stream);
+    if (c == 128 && w == 64) return launch_t16<128, 64, DT>(k, next, n_tiles, stream);
+    if (c == 64 && w == 128) return launch_t16<64, 128, DT>(k, next, n_tiles, stream);
+    return vqae::fail(VQAE_ERR_UNSUPPORTED, "trunk16: C = %d on a %d-wide grid", c, w);
+}
+
+}  // namespace
+
+namespace vqae {
+
+// (C, grid width) pairs with a kernel: the trunk of cfg A / B (128 @ 32), cfg C (256 @ 32) and the levels above them
+bool trunk16_supported(int c, int h, int w, int dtype) {
+    static const bool off = getenv("VQAE_NO_TRUNK16") && atoi(getenv("VQAE_NO_TRUNK16"));
+    if (off || (dtype != VQAE_DT_BF16 && dtype != VQAE_DT_F16)) return false;
+    const bool cw = (c == 128 && w == 32) || (c == 256 && w == 32) || (c == 64 && w == 64) || (c == 128 && w == 64) ||
+                    (c == 64 && w == 128);
+    return cw && h >= 1 && h % (128 / w) == 0;
+}
+
+// + the ring's look-ahead past the last n-tile's fragments (trunk16_kernel reads, never uses, NB KiB beyond them)
+size_t trunk16_weight_bytes(int c, int taps) { return (size_t)c * c * taps * 2 + (size_t)(NB_MAX + 1) * 1024; }
+
+// packed (vqae_conv_pack_weight_f32, rounded) fp32 weights [c][taps * c] on the device -> 16-bit fragment order
+int trunk16_pack_weight(const float* w_packed_dev, int c, int taps, int dtype, void* out_dev, hipStream_t stream) {
+    VQAE_REQUIRE(c % 32 == 0 && (taps == 1 || taps == 9), VQAE_ERR_INVALID, "trunk16_pack_weight: c %d taps %d", c, taps);
+    const int64_t n = (int64_t)c * c * taps;
+    if (dtype == VQAE_DT_BF16) pack16_kernel<__bf16><<<(unsigned)ceil_div(n, 256), 256, 0, stream>>>(w_packed_dev, c, taps, (__bf16*)out_dev);
+    else pack16_kernel<_Float16><<<(unsigned)ceil_div(n, 256), 256, 0, stream>>>(w_packed_dev, c, taps, (_Float16*)out_dev);
+    VQAE_LAUNCH_CHECK();
+    return VQAE_OK;
+}
+
+// fp32 [n] (n % 4 == 0) -> 16-bit, RNE: t1 of a chain head produced by the generic conv1 launch
+int trunk16_round_pack(const float* src, void* dst, int64_t n, int dtype, hipStream_t stream) {
+    VQAE_REQUIRE(n % 4 == 0, VQAE_ERR_INVALID, "trunk16_round_pack: n %% 4");
+    const int64_t n4 = n / 4;
+    if (dtype == VQAE_DT_BF16) round_pack16_kernel<__bf16><<<(unsigned)ceil_div(n4, 256), 256, 0, stream>>>(src, (__bf16*)dst, n4);
+    else round_pack16_kernel<_Float16><<<(unsigned)ceil_div(n4, 256), 256, 0, stream>>>(src, (_Float16*)dst, n4);
+    VQAE_LAUNCH_CHECK();
+    return VQAE_OK;
+}
+
+// One trunk Fixup block: t1 (16-bit) -> xio updated in place (+ t1_next, 16-bit, when w1nf != null).
+int trunk16_block(const void* t1, const void* w2f, const void* w3f, float act_a, float act_b, float t_scale, float t_b4,
+                  float* xio, const void* w1nf, float n_b1a, float n_b1b, float n_b2a, float n_b2b, void* t1_next,
+                  int batch, int h, int w, int c, int dtype, hipStream_t stream) {
+    if (batch == 0) return VQAE_OK;
+    VQAE_REQUIRE(t1 && w2f && w3f && xio && (!w1nf || t1_next), VQAE_ERR_INVALID, "trunk16_block: null pointer");
+    VQAE_REQUIRE(trunk16_supported(c, h, w, dtype), VQAE_ERR_UNSUPPORTED, "trunk16_block: C = %d, H = %d, W = %d, dtype %d", c, h, w, dtype);
+    const int64_t M = (int64_t)batch * h * w;
+    VQAE_REQUIRE(M / 128 < (1ll << 31) - 8, VQAE_ERR_UNSUPPORTED, "trunk16_block: too many pixels");
+    T16K k;
+    k.t1 = t1; k.w2f = w2f; k.w3f = w3f; k.w1nf = w1nf; k.xio = xio; k.t1n = t1_next; k.H = h;
+    k.act_a = act_a; k.act_b = act_b; k.t_scale = t_scale; k.t_b4 = t_b4;
+    k.n_b1a = n_b1a; k.n_b1b = n_b1b; k.n_b2a = n_b2a; k.n_b2b = n_b2b;
+    const int n_tiles = (int)(M / 128);
+    if (dtype == VQAE_DT_BF16) return launch_t16_cw<VQAE_DT_BF16>(k, w1nf != nullptr, c, w, n_tiles, stream);
+    return launch_t16_cw<VQAE_DT_F16>(k, w1nf != nullptr, c, w, n_tiles, stream);
+}
+
+}  // namespace vqae
+
+#ifdef VQAE_T16_TRACE
+extern "C" int vqae_debug_t16_trace(void* dev_buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_t16_trace), &dev_buf, sizeof(dev_buf)) == hipSuccess ? 0 : -3;
+}
+#endif

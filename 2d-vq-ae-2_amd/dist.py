@@ -46,6 +46,25 @@ def shard_range(n: int, rank: int, world_size: int) -> Tuple[int, int]:
     return lo, lo + q + (1 if rank < r else 0)
 
 
+def gather_capacity(batch_size: int, world_size: int) -> int:
+    """Tiles a rank can own of one global batch (= the share of rank 0)."""
+    return -(-batch_size // world_size)
+
+
+def all_gather_shares(mine: torch.Tensor, async_op: bool = False):
+    """The data path's only collective.  `mine` [cap, row_bytes] uint8: this rank's share of one batch (code tiles +
+    pooled label tiles, packed), zero-padded to the fixed per-rank capacity -> (out [world, cap, row_bytes], work).
+    Sizes are fixed by (batch_size, world_size) and every rank knows every share's length from shard_range, so there
+    is no size exchange and no host sync; with async_op the gather (RCCL: its own stream) overlaps the next batch."""
+    rank, ws = world()
+    out = mine.new_empty((ws,) + tuple(mine.shape))
+    if ws == 1:
+        out[0].copy_(mine)
+        return out, None
+    work = dist.all_gather_into_tensor(out.view(-1), mine.contiguous().view(-1), async_op=async_op)
+    return out, work
+
+
 def all_gather_ragged(x: torch.Tensor) -> List[torch.Tensor]:
     """All-gather tensors whose first dimension differs per rank (last, short batch of a slide).
     One size exchange + one padded all_gather_into_tensor; returns the per-rank tensors in rank order."""

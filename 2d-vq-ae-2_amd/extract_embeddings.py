@@ -7,13 +7,15 @@ ingestion, label max-pooling, and patch-batch sharding over ranks (dist.py).
 
 Out of scope: Hydra/Lightning checkpoint discovery (`main`, `find_ckpt_folder`).
 """
+import contextlib
 import os
 from pathlib import Path
 from typing import Iterator, Optional, Tuple
 
 import numpy as np
 import torch
-from torch.utils.data import DataLoader, Dataset
+from torch.utils.data import DataLoader, Dataset, Sampler
+from torch.utils.data.dataloader import default_collate
 
 from . import dist as vdist
 from . import hdf5
@@ -87,17 +89,25 @@ def _extract_path(path: str) -> str:                 # extract_embeddings.py:111
     return Path(path).parent.stem + '/' + Path(path).stem
 
 
-def _encode(model, imgs):
+_REF_AUTOCAST = torch.float16        # `with torch.autocast('cuda')` (extract_embeddings.py:124): CUDA autocast defaults to fp16
+
+
+def _encode(model, imgs, autocast_dtype=_REF_AUTOCAST):
     """indices [B, h, w] from whatever was passed: NativeVQAE, or a module with `.encoder`
-    (reference contract: `tuple(zip(*model.encoder(imgs)))[0]` = (q, idx, loss), :125)."""
-    if hasattr(model, "encode_u8") and imgs.dtype == torch.uint8:
-        return model.encode_u8(imgs)[1]
-    if hasattr(model, "encode"):
-        return model.encode(imgs, "NCHW", want_q=False, want_loss=False)[1]
-    nat = getattr(model, "native", None)
-    if imgs.dtype == torch.uint8 and nat is not None:
-        return nat().encode_u8(imgs)[1]
-    _, idx, _ = tuple(zip(*model.encoder(imgs)))[0]
+    (reference contract: `tuple(zip(*model.encoder(imgs)))[0]` = (q, idx, loss), :125), with the convolutions
+    in `autocast_dtype` (None = fp32): a NativeVQAE switches to the handle of that compute dtype, a module mirror
+    runs inside `torch.autocast('cuda', dtype)` exactly as the reference wraps its encoder (:124-125)."""
+    if hasattr(model, "with_dtype"):                               # NativeVQAE
+        nat = model.with_dtype(autocast_dtype)
+        if imgs.dtype == torch.uint8:
+            return nat.encode_u8(imgs)[1]
+        return nat.encode(imgs, "NCHW", want_q=False, want_loss=False)[1]
+    ctx = torch.autocast("cuda", dtype=autocast_dtype) if autocast_dtype is not None else contextlib.nullcontext()
+    with ctx:
+        nat = getattr(model, "native", None)
+        if imgs.dtype == torch.uint8 and nat is not None:
+            return nat().encode_u8(imgs)[1]
+        _, idx, _ = tuple(zip(*model.encoder(imgs)))[0]
     return idx
 
 
@@ -110,46 +120,162 @@ def _factor(model) -> int:
     raise TypeError("run_eval: model must be a NativeVQAE or a vqae_amd.model.{VQAE,Encoder}")
 
 
+def _num_codes(model) -> Optional[int]:
+    spec = getattr(model, "spec", None)
+    if spec is None and hasattr(model, "_spec"):
+        spec = model._spec()
+    return int(spec.num_embeddings) if spec is not None else None
+
+
+def batch_meta(dataset, lo: int, hi: int):
+    """(img_index [n] int64, patch_index [n, 2] int64, image paths, mask paths) of items [lo, hi) WITHOUT reading a
+    pixel: the index -> (slide, row, col) rule of CAMELYON16SlicePatchDataSet.__getitem__ (camelyon16.py:184-190:
+    bisect over `_cum_lengths`, row = i // cols, col = i % cols), which the default collate would otherwise deliver."""
+    idx = np.arange(lo, hi, dtype=np.int64)
+    cum = np.asarray(dataset._cum_lengths, dtype=np.int64)
+    sizes = np.asarray(dataset._sizes, dtype=np.int64)
+    img = np.searchsorted(cum, idx, side="right")                        # bisect.bisect
+    first = np.where(img > 0, cum[np.maximum(img - 1, 0)], 0)
+    local = idx - first
+    cols = sizes[img, 1]
+    patch = np.stack([local // cols, local % cols], 1)
+    ip, mp = np.asarray(dataset.image_paths), np.asarray(dataset.mask_paths)
+    return torch.from_numpy(img), torch.from_numpy(patch), [str(v) for v in ip[img]], [str(v) for v in mp[img]]
+
+
+class ShardBatchSampler(Sampler):
+    """Batch sampler of one rank: of every global batch [k * bs, (k + 1) * bs) it yields only this rank's contiguous
+    share (dist.shard_range), so a rank's loader workers read only the tiles that rank encodes -- host loading is
+    divided over the ranks, not replicated.  Every rank walks the same number of batches (a share may be empty)."""
+
+    def __init__(self, n, batch_size, rank, world_size):
+        self.n, self.bs, self.rank, self.ws = int(n), int(batch_size), rank, world_size
+
+    def __len__(self):
+        return -(-self.n // self.bs)
+
+    def __iter__(self):
+        for b0 in range(0, self.n, self.bs):
+            lo, hi = vdist.shard_range(min(self.bs, self.n - b0), self.rank, self.ws)
+            yield list(range(b0 + lo, b0 + hi))
+
+
+def _collate(batch):
+    return default_collate(batch) if batch else None
+
+
+def _pool_labels(lab, out_hw):
+    """adaptive_max_pool2d(labels, encoding grid) (extract_embeddings.py:127-130) on the device."""
+    return ops.label_maxpool(lab.reshape(lab.shape[0], lab.shape[-2], lab.shape[-1]).to(torch.uint8), out_hw)
+
+
 @torch.no_grad()
-def run_eval(model, dataset, batch_size=100, num_workers=0, device=None, shard=True):
-    """Batched encoder pass (extract_embeddings.py:92-138).  Yields, per batch, the reference's pair
+def run_eval(model, dataset, batch_size=100, *, autocast_dtype=_REF_AUTOCAST, num_workers=6, prefetch_factor=5,
+             device=None, shard=True, encode_fn=None, pool_fn=None):
+    """Batched encoder pass: drop-in for run_eval (extract_embeddings.py:92-138).  Yields, per batch, the reference's pair
         ((encoding_indices, names, img_index, patch_index), (labels_pooled, names, img_index, patch_index))
-    with tensors on `device`.  Under torch.distributed each rank encodes a contiguous share of every
-    batch and the code tiles are re-assembled with one all-gather (dist.all_gather_codes), so every
-    rank yields the full batch in the original order."""
-    device = device or torch.device("cuda")
+    with tensors on `device`.  Defaults are the reference's: batch 100, 6 loader workers, prefetch 5, pinned memory
+    (:95-101), the encoder under fp16 autocast (:124-125; pass autocast_dtype=None for fp32 convolutions, or
+    torch.bfloat16).
+
+    Under torch.distributed (one process per GPU) every global batch is sharded contiguously over the ranks: a
+    rank's loader reads and its GPU encodes only its share (ShardBatchSampler); the shares are re-assembled with ONE
+    fixed-size all-gather per batch (dist.all_gather_shares: uint8 / uint16 code tiles + pooled label tiles in one
+    buffer, no size exchange, no host sync), issued asynchronously so it overlaps the next batch's encoder pass.
+    Every rank yields the full batch in the original order.
+
+    encode_fn(imgs_on_device) -> indices [b, h, w] and pool_fn(labels_on_device, out_hw) -> [b, out_hw, out_hw]
+    replace the HIP encoder / max-pool (used by the CPU tests of the sharded path; the product default has no
+    CPU fallback and raises without a GPU)."""
+    device = torch.device(device) if device is not None else torch.device("cuda")
     rank, ws = vdist.world() if shard else (0, 1)
-    loader = DataLoader(dataset, batch_size=batch_size, pin_memory=True, num_workers=num_workers,
-                        **({"prefetch_factor": 5} if num_workers else {}))
-    factor = _factor(model)
-    for imgs, labels, (img_index, patch_index, img_path, label_path) in loader:
-        n = imgs.shape[0]
-        lo, hi = vdist.shard_range(n, rank, ws)
-        x = imgs[lo:hi].to(device, non_blocking=True)
-        lab = labels[lo:hi].to(device, non_blocking=True)
-        idx = _encode(model, x) if hi > lo else None
-        out_hw = (imgs.shape[1] if imgs.dtype == torch.uint8 else imgs.shape[2]) // factor
-        if idx is None:
-            idx = torch.empty((0, out_hw, out_hw), dtype=torch.int64, device=device)
-        pooled = ops.label_maxpool(lab.reshape(hi - lo, lab.shape[-2], lab.shape[-1]).to(torch.uint8), out_hw) \
-            if hi > lo else torch.empty((0, out_hw, out_hw), dtype=torch.uint8, device=device)
-        if ws > 1:
-            meta = torch.stack([img_index[lo:hi].to(torch.int64), patch_index[lo:hi, 0].to(torch.int64),
-                                patch_index[lo:hi, 1].to(torch.int64)], 1).to(device)
-            compact = idx.to(torch.int32)
-            idx, _ = vdist.all_gather_codes(compact, meta)
-            idx = idx.to(torch.int64)
-            pooled, _ = vdist.all_gather_codes(pooled, meta)
-        yield (
-            (data, list(map(_extract_path, paths)), img_index, patch_index)
-            for data, paths in ((idx, img_path), (pooled.to(labels.dtype), label_path))
-        )
+    enc = encode_fn or (lambda x: _encode(model, x, autocast_dtype))
+    pool = pool_fn or _pool_labels
+    pin = device.type == "cuda"
+    extra = {"prefetch_factor": prefetch_factor} if num_workers else {}
+    if ws > 1:
+        loader = DataLoader(dataset, batch_sampler=ShardBatchSampler(len(dataset), batch_size, rank, ws),
+                            collate_fn=_collate, pin_memory=pin, num_workers=num_workers, **extra)
+    else:
+        loader = DataLoader(dataset, batch_size=batch_size, pin_memory=pin, num_workers=num_workers, **extra)
+    factor = _factor(model) if encode_fn is None else None
+    n_codes = _num_codes(model) if model is not None else None
+    code_bytes = 1 if (n_codes or 1 << 30) <= 256 else (2 if (n_codes or 1 << 30) <= 65536 else 4)
+    code_dtype = {1: torch.uint8, 2: torch.int16, 4: torch.int32}[code_bytes]
+    cap = vdist.gather_capacity(batch_size, ws)
+
+    def finish(item):
+        """gathered buffer -> the reference's generator of two tuples, for one batch"""
+        (out, work, n, th, tw, meta, labels_dtype) = item
+        if work is not None:
+            work.wait()
+        idx_parts, pool_parts = [], []
+        nb = th * tw * code_bytes
+        for r in range(ws):
+            lo, hi = vdist.shard_range(n, r, ws)
+            rows = out[r, : hi - lo]
+            idx_parts.append(rows[:, :nb].contiguous().view(code_dtype).reshape(hi - lo, th, tw))
+            pool_parts.append(rows[:, nb:].reshape(hi - lo, th, tw))
+        idx = torch.cat(idx_parts, 0).to(torch.int64)
+        if code_bytes == 2:
+            idx = idx & 0xFFFF                                     # uint16 codes travelled as int16 bit patterns
+        pooled = torch.cat(pool_parts, 0).to(labels_dtype)
+        img_index, patch_index, img_path, label_path = meta
+        return ((data, list(map(_extract_path, paths)), img_index, patch_index)
+                for data, paths in ((idx, img_path), (pooled, label_path)))
+
+    pending, grid_hw = None, None
+    for k, batch in enumerate(loader):
+        if ws == 1:
+            imgs, labels, (img_index, patch_index, img_path, label_path) = batch
+            x = imgs.to(device, non_blocking=True)
+            lab = labels.to(device, non_blocking=True)
+            idx = enc(x)
+            pooled = pool(lab, idx.shape[-1]).to(labels.dtype)
+            yield ((data, list(map(_extract_path, paths)), img_index, patch_index)
+                   for data, paths in ((idx, img_path), (pooled.reshape(idx.shape), label_path)))
+            continue
+        # ---- sharded: encode my share, pack, launch the gather, and only then hand out the PREVIOUS batch ----------
+        b0 = k * batch_size
+        n = min(batch_size, len(dataset) - b0)
+        meta = batch_meta(dataset, b0, b0 + n)
+        if batch is not None:
+            imgs, labels, _ = batch
+            x = imgs.to(device, non_blocking=True)
+            lab = labels.to(device, non_blocking=True)
+            idx = enc(x)
+            th, tw = int(idx.shape[-2]), int(idx.shape[-1])
+            pooled = pool(lab, tw).reshape(idx.shape[0], th * tw).to(torch.uint8)
+            codes = idx.to(code_dtype).reshape(idx.shape[0], th * tw).contiguous().view(torch.uint8)
+            mine = torch.zeros((cap, codes.shape[1] + pooled.shape[1]), dtype=torch.uint8, device=device)
+            mine[: idx.shape[0], : codes.shape[1]] = codes
+            mine[: idx.shape[0], codes.shape[1]:] = pooled
+            labels_dtype = labels.dtype
+            grid_hw = (th, tw, labels_dtype)
+        else:                                                      # empty share (a last batch shorter than the world size)
+            if grid_hw is None:                                    # ... before this rank ever encoded a tile
+                ps = getattr(dataset, "patch_size", None)
+                assert factor is not None and ps is not None, "run_eval: an empty share needs dataset.patch_size and a model factor"
+                grid_hw = (int(ps[0]) // factor, int(ps[1]) // factor, torch.uint8)
+            th, tw, labels_dtype = grid_hw
+            mine = torch.zeros((cap, th * tw * (code_bytes + 1)), dtype=torch.uint8, device=device)
+        out, work = vdist.all_gather_shares(mine, async_op=True)
+        if pending is not None:
+            yield finish(pending)
+        pending = (out, work, n, th, tw, meta, labels_dtype)
+    if pending is not None:
+        yield finish(pending)
 
 
-def get_encodings(model, dataset, batch_size=100, **kw) -> Iterator[Tuple[str, np.ndarray]]:
+def _stitch(sel, rc, grid):
+    return ops.stitch_tiles(sel, rc, grid)
+
+
+def get_encodings(model, dataset, batch_size=100, stitch_fn=None, **kw) -> Iterator[Tuple[str, np.ndarray]]:
     """Stitch code tiles into one `[32*rows, 32*cols]` grid per slide on the device and yield
     `(name, ndarray)` -- cast to the lowest dtype -- as soon as every tile of a slide has been seen
-    (extract_embeddings.py:43-89)."""
+    (extract_embeddings.py:43-89).  `stitch_fn(tiles, rc, grid)` replaces the HIP scatter (CPU tests only)."""
+    stitch = stitch_fn or _stitch
     arrays, counts = {}, {}
     for ret_values in run_eval(model, dataset, batch_size=batch_size, **kw):
         for (encodings, names, img_idx, patch_idx) in ret_values:
@@ -165,7 +291,7 @@ def get_encodings(model, dataset, batch_size=100, **kw) -> Iterator[Tuple[str, n
                 mask = torch.as_tensor(img_idx_np == image_index)
                 sel = encodings[mask.to(encodings.device)]
                 rc = torch.as_tensor(np.asarray(patch_idx)[mask.numpy()], dtype=torch.int32, device=encodings.device)
-                ops.stitch_tiles(sel, rc, arrays[name])                    # device scatter (:83-84)
+                stitch(sel, rc, arrays[name])                              # device scatter (:83-84)
                 counts[name] -= int(count)
                 if counts[name] == 0:
                     counts.pop(name)

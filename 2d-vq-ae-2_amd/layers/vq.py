@@ -13,6 +13,15 @@ from .. import _lib as L
 from .. import ops
 
 
+def fused_all_reduce_stats(counts, dw):
+    """`all_reduce(new_cluster_size)` + `all_reduce(dw)` of _update_ema (vq.py:57-58) as ONE all-reduce of the flat
+    [K] + [K * D] buffer (latency-bound messages: 1 KB + 8..128 KB).  Element-wise SUM: fusing changes no element's
+    reduction, only the number of collectives (tests/test_driver_cpu.py checks equality under 2 ranks)."""
+    flat = torch.cat([counts.reshape(-1), dw.reshape(-1)])
+    torch.distributed.all_reduce(flat)
+    return flat[: counts.numel()].reshape_as(counts), flat[counts.numel():].reshape_as(dw)
+
+
 class EMAVectorQuantizer(nn.Module):
     def __init__(self, num_embeddings: int, embedding_dim: int, commitment_cost: float, decay: float,
                  laplace_alpha: float):
@@ -36,10 +45,7 @@ class EMAVectorQuantizer(nn.Module):
     def _update_ema(self, flat_input, encoding_indices):
         counts, dw = ops.vq_code_stats(flat_input, encoding_indices, self.num_embeddings)
         if torch.distributed.is_available() and torch.distributed.is_initialized():
-            # one fused all-reduce of [K] + [K*D] instead of the reference's two (vq.py:57-58)
-            flat = torch.cat([counts, dw.reshape(-1)])
-            torch.distributed.all_reduce(flat)
-            counts, dw = flat[: self.num_embeddings], flat[self.num_embeddings:].reshape_as(dw)
+            counts, dw = fused_all_reduce_stats(counts, dw)
         ops.vq_ema_update(self.embed, self.embed_avg, self.cluster_size, counts.contiguous(), dw.contiguous(),
                           self.decay, self.laplace_alpha)
 

@@ -24,14 +24,15 @@ class NativeVQAE:
                        spec.num_embeddings, spec.projection_dim, float(spec.commitment_cost), self.compute_dtype,
                        L.BLOCK_MBCONV if spec.block == "mbconv" else L.BLOCK_FIXUP, spec.expand_ratio,
                        spec.se_divisor, float(spec.bn_eps))
-        keep, items = [], []
+        self._state, items = {}, []             # host copies (fp32): siblings in other compute dtypes are built from them
         for name, t in state_dict.items():
             if name.endswith(_BUFFER_ONLY):
                 continue
             a = np.ascontiguousarray(t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t),
                                      dtype=np.float32)
-            keep.append(a)
+            self._state[name] = a
             items.append(L.Tensor(name.encode(), a.ctypes.data_as(ctypes.c_void_p), a.size))
+        self._siblings = {}
         arr = (L.Tensor * len(items))(*items)
         h = ctypes.c_void_p()
         L.check(L.lib().vqae_create(ctypes.byref(cfg), arr, len(items), ctypes.byref(h)))
@@ -39,7 +40,21 @@ class NativeVQAE:
         self.channels = spec.channels
         self.factor = 2 ** spec.n_down
 
+    def with_dtype(self, compute_dtype):
+        """The handle of the same weights with another conv compute dtype (None / 'f32' / 'bf16' / 'f16' / torch
+        dtypes), built on first use and cached: `with torch.autocast('cuda', dtype)` of the reference's run_eval
+        (extract_embeddings.py:124-125) maps to `nat.with_dtype(dtype)`."""
+        code = L.dtype_code(compute_dtype)
+        if code == self.compute_dtype:
+            return self
+        if code not in self._siblings:
+            self._siblings[code] = NativeVQAE(self.spec, self._state, compute_dtype=code)
+        return self._siblings[code]
+
     def close(self):
+        for sib in getattr(self, "_siblings", {}).values():
+            sib.close()
+        self._siblings = {}
         if getattr(self, "_h", None):
             L.lib().vqae_destroy(self._h)
             self._h = None
@@ -59,6 +74,9 @@ class NativeVQAE:
                                  dtype=np.float32)
         assert a.shape == (self.spec.num_embeddings, self.spec.code_dim), a.shape
         L.check(L.lib().vqae_set_codebook(self._h, a.ctypes.data_as(ctypes.c_void_p)))
+        self._state["encoder.vq_layers.0.embed"] = a.copy()
+        for sib in self._siblings.values():
+            sib.set_codebook(a)
 
     @staticmethod
     def _layout(x, layout):

@@ -352,7 +352,7 @@ if __name__ == "__main__":
         gen_model("BM", 2, 256, False)
     if "taps" in todo:
         print("G9 per-block taps (mid-size models reaching the production kernels)")
-        for nm in ("mid", "mid16", "midA"):
+        for nm in ("mid", "mid16", "midA", "midC"):
             gen_model_taps(nm, 2, 128, None, "f32")
             gen_model_taps(nm, 2, 128, torch.bfloat16, "bf16")
             gen_model_taps(nm, 2, 128, torch.float16, "f16")

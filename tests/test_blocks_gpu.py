@@ -16,8 +16,10 @@ block input and compared with the oracle's block output over the FULL tensor.
 Bars: fp32 -- max |err| <= 2e-5 * max(1, max|ref|) per block (summation order differs from oneDNN's);
 16-bit -- conv operands / outputs are rounded to the 16-bit type on both sides, so outputs are equal except where an
 fp32 accumulation lands within summation-order noise of a 16-bit rounding boundary: isolated 1-ulp(16) flips of a
-conv output.  A block has three chained convs, so a flip in conv1 perturbs a few conv2 inputs, etc.: <= 3 % of the
-elements may differ by more than 1e-5 * scale, none by more than 8 ulp16 * scale.
+conv output.  A block has three chained convs and one flipped conv2 input moves 9 C products by a fraction of an
+ulp16 each, so a flip in conv1 breeds a few more downstream (measured: up to 4.9 % of a block's elements at C = 256 in
+f16, 0.7 % in bf16): <= 8 % of the elements may differ by more than 1e-5 * scale, and NONE by more than 3 ulp16 * scale
+(measured worst: 1.3 ulp16; a wrong weight, lane or pixel gives errors of the order of the branch itself, 30-300 ulp16).
 """
 import numpy as np
 import pytest
@@ -41,9 +43,19 @@ def oracle_taps(oracle, name, tag):
     p = oracle.make_params(spec, 0)
     p["encoder.vq_layers.0.embed"] = torch.from_numpy(g["embed"])
     x = oracle.make_patches(int(g["batch"]), int(g["size"]), 0)
+    # encoder taps from x; decoder taps from the REFERENCE's indices (q = codebook lookup [+ proj_out]): on another CPU
+    # the 16-bit encoder flips a few near-tie indices, which would change q wholesale and make the decoder taps
+    # incomparable with the fixture.  (embed[idx] differs from the reference's x + (q - x) by <= 1 fp32 ulp.)
+    import contextlib
     taps = {}
-    out, _ = oracle.vqae_forward(x, p, spec, taps, dtype=TDT[tag])
-    taps["out"] = out
+    with (torch.autocast("cpu", dtype=TDT[tag]) if TDT[tag] is not None else contextlib.nullcontext()):
+        oracle.encoder_forward(x, p, spec, taps)
+        vq = "encoder.vq_layers.0."
+        q = p[vq + "embed"][torch.from_numpy(g["idx"].astype(np.int64))].permute(0, 3, 1, 2).contiguous()
+        if spec.projection_dim > 0:
+            q = torch.nn.functional.conv2d(q, p[vq + "proj_out.weight"], p[vq + "proj_out.bias"])
+        taps["q"] = q
+        taps["out"] = oracle.decoder_forward((q,), p, spec, taps)
     # the GPU box's CPU may take other oneDNN kernels than the container the fixture was recorded in: allow
     # summation-order noise (fp32) / isolated 16-bit rounding flips here; bit-exactness is the CPU suite's job
     for k in g.files:
@@ -54,8 +66,9 @@ def oracle_taps(oracle, name, tag):
         err = np.abs(got - ref)
         if tag == "f32":
             assert err.max() <= 1e-5 * scale, (k, err.max())
-        else:
-            assert (err > 1e-5 * scale).mean() <= 0.03 and err.max() <= 8 * ULP[tag] * scale, (k, err.max())
+        else:                # the taps are cumulative (each block runs on the chain's own previous output): flips add up
+            rms = float(np.sqrt((err.astype(np.float64) ** 2).mean() / (ref.astype(np.float64) ** 2).mean()))
+            assert rms <= 4 * ULP[tag], (k, rms)
     _cache[key] = (spec, p, x, {k: v.float() for k, v in taps.items() if torch.is_tensor(v)})
     return _cache[key]
 
@@ -73,7 +86,7 @@ def compare(got_nhwc, ref_nchw, tag, n_blocks):
     if tag == "f32":
         ok = mx <= 2e-5 * scale * n_blocks
     else:
-        ok = frac <= 0.03 * n_blocks and mx <= 8 * ULP[tag] * scale * n_blocks
+        ok = frac <= 0.08 * n_blocks and mx <= 3 * ULP[tag] * scale * n_blocks
     return ok, mx / scale, frac
 
 
@@ -82,7 +95,7 @@ def block_lists(oracle, spec):
 
 
 @pytest.mark.parametrize("tag", ["f32", "bf16", "f16"])
-@pytest.mark.parametrize("name", ["mid", "mid16", "midA"])
+@pytest.mark.parametrize("name", ["mid", "mid16", "midA", "midC"])
 def test_production_blocks_match_oracle_per_block(amd, oracle, name, tag):
     """Every block alone (count = 1): conv1 launch + fused tail without the next-block conv1, 'down' / 'up' blocks."""
     spec, p, x, taps = oracle_taps(oracle, name, tag)
@@ -105,40 +118,82 @@ def test_production_blocks_match_oracle_per_block(amd, oracle, name, tag):
     assert not bad, bad
 
 
+def autocast_ctx(tag):
+    import contextlib
+    return torch.autocast("cpu", dtype=TDT[tag]) if TDT[tag] is not None else contextlib.nullcontext()
+
+
 @pytest.mark.parametrize("tag", ["f32", "bf16", "f16"])
-@pytest.mark.parametrize("name", ["mid", "mid16", "midA"])
+@pytest.mark.parametrize("name", ["mid", "mid16", "midA", "midC"])
+def test_fused_next_conv1_on_identical_inputs(amd, oracle, name, tag):
+    """The cross-block fusion (conv2 + conv3 + the NEXT block's conv1 in one launch; t1 handed from launch to launch,
+    as 16-bit in the 16-bit modes) on identical inputs: for every pair of consecutive blocks, y1 = blocks[i] alone and
+    y2 = blocks[i, i+1] in one run (block i+1 then takes its t1 from block i's fused tail); the oracle evaluates block
+    i+1 on the GPU's own y1, so y2 is compared with a reference that saw bit-identical input.  Per-block bars."""
+    spec, p, x, taps = oracle_taps(oracle, name, tag)
+    nat = amd.NativeVQAE(amd.SPECS[name], p, compute_dtype=None if tag == "f32" else tag)
+    bad, worst, n = [], (0.0, 0.0, ""), 0
+    for side, blocks, first_in in block_lists(oracle, spec):
+        ins = [taps[first_in]] + [taps[b[0]] for b in blocks[:-1]]
+        for i in range(len(blocks) - 1):
+            xin = nhwc(ins[i]).cuda()
+            y1 = nat.run_blocks(side, i, 1, xin)
+            y2 = nat.run_blocks(side, i, 2, xin)
+            with autocast_ctx(tag):
+                ref2 = oracle.conv_block(y1.permute(0, 3, 1, 2).cpu(), p, blocks[i + 1][0], blocks[i + 1][1], spec).float()
+            ok, rel, frac = compare(y2, ref2, tag, 1)
+            n += 1
+            if not ok:
+                bad.append((blocks[i + 1][0], blocks[i + 1][1], rel, frac))
+            if rel > worst[0]:
+                worst = (rel, frac, blocks[i + 1][0])
+    record_parity("fused_pairs_identical_input", model=name, dtype=tag, pairs=n, failed=len(bad), worst_rel_err=worst[0],
+                  worst_frac_off=worst[1], worst_block=worst[2])
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("tag", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("name", ["mid", "mid16", "midA", "midC"])
 def test_production_block_chains_match_oracle(amd, oracle, name, tag):
-    """Runs of consecutive blocks (count = 2, and every maximal chain of 'same' blocks of one width): the fused
-    conv2 + conv3 + NEXT-block conv1 tails (t1 handed from launch to launch) and the chain-head conv1 kernels."""
+    """Every maximal chain of same-width 'same' blocks in one run (the production dispatch: chain-head conv1 + one
+    fused launch per block) against the oracle's chain.  In fp32 the per-block bar scales with the chain length.  In
+    16-bit a chain is NOT comparable element by element: one rounding flip at a conv input moves ~9 C products by a
+    fraction of an ulp16 each and so flips further outputs (a branching process with mean > 1), i.e. after a few convs
+    most elements differ -- by about one ulp16 of the branch.  The bar there is on magnitude: no element further than
+    4 ulp16 * sqrt(blocks) * scale, mean |err| <= ulp16 * scale / 2 (a wrong weight / lane gives errors of the order
+    of the branch itself, 10-100x more)."""
     spec, p, x, taps = oracle_taps(oracle, name, tag)
     nat = amd.NativeVQAE(amd.SPECS[name], p, compute_dtype=None if tag == "f32" else tag)
     bad, worst, n_runs = [], (0.0, 0.0, ""), 0
     for side, blocks, first_in in block_lists(oracle, spec):
         ins = [taps[first_in]] + [taps[b[0]] for b in blocks[:-1]]
-        runs = [(i, 2) for i in range(len(blocks) - 1)]
-        i = 0
+        runs, i = [], 0
         while i < len(blocks):                         # maximal chains of same-width 'same' blocks
             j = i
             while j + 1 < len(blocks) and blocks[j + 1][1] == "same" and blocks[j][1] == "same" and blocks[j + 1][2] == blocks[i][2]:
                 j += 1
-            if j - i + 1 >= 3:
+            if j - i + 1 >= 2:
                 runs.append((i, j - i + 1))
             i = j + 1
         for first, count in runs:
-            y = nat.run_blocks(side, first, count, nhwc(ins[first]).cuda())
-            ok, rel, frac = compare(y, taps[blocks[first + count - 1][0]], tag, count)
+            y = nat.run_blocks(side, first, count, nhwc(ins[first]).cuda()).permute(0, 3, 1, 2).cpu()
+            ref = taps[blocks[first + count - 1][0]]
+            err = (y - ref).abs()
+            scale = max(1.0, float(ref.abs().max()))
+            mx, mean = float(err.max()) / scale, float(err.mean()) / scale
+            ok = mx <= 2e-5 * count if tag == "f32" else (mx <= 4 * ULP[tag] * count ** 0.5 and mean <= 0.5 * ULP[tag])
             n_runs += 1
             if not ok:
-                bad.append((blocks[first][0], count, rel, frac))
-            if rel > worst[0]:
-                worst = (rel, frac, f"{blocks[first][0]}+{count}")
-    record_parity("block_chains", model=name, dtype=tag, runs=n_runs, failed=len(bad), worst_rel_err=worst[0],
-                  worst_frac_off=worst[1], worst_run=worst[2])
+                bad.append((blocks[first][0], count, mx, mean))
+            if mx > worst[0]:
+                worst = (mx, mean, f"{blocks[first][0]}+{count}")
+    record_parity("block_chains", model=name, dtype=tag, runs=n_runs, failed=len(bad), worst_max_rel_err=worst[0],
+                  its_mean_rel_err=worst[1], worst_run=worst[2])
     assert not bad, bad
 
 
 @pytest.mark.parametrize("tag", ["f32", "bf16", "f16"])
-@pytest.mark.parametrize("name", ["mid", "mid16", "midA"])
+@pytest.mark.parametrize("name", ["mid", "mid16", "midA", "midC"])
 def test_mid_models_end_to_end_vs_reference(amd, oracle, name, tag):
     """Whole forward of the mid-size models against the reference's recorded indices / output samples."""
     g = load_golden(f"taps_{name}_{tag}")

@@ -84,3 +84,169 @@ def test_all_gather_codes_gloo_world2(amd):
     assert sorted(r[0] for r in res) == [0, 1]
     assert all(r[1] for r in res)
     assert {(r[2], r[3]) for r in res} == {(0, 4), (4, 7)}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The sharded driver end to end under gloo, world_size 2: run_eval -> get_encodings on two interleaved slides against
+# the reference's own get_encodings output (tests/golden/driver.npz).  The HIP encoder / max-pool / scatter are
+# replaced by table look-ups through the injection points (encode_fn, pool_fn, stitch_fn): this exercises the
+# sampler, the packing, the single gather per batch, the pipelining by one batch and the slide assembly, not kernels.
+class _FixtureSlides(torch.utils.data.Dataset):
+    """Items carry their own index; geometry as CAMELYON16SlicePatchDataSet (_sizes, _lengths, _cum_lengths, paths)."""
+
+    def __init__(self, sizes, label_hw=8):
+        self._sizes = np.asarray(sizes, dtype=np.int64)
+        self._lengths = self._sizes.prod(axis=-1)
+        self._cum_lengths = np.cumsum(self._lengths)
+        self.image_paths = ["/data/images/slide_a.tif", "/data/images/slide_b.tif"]
+        self.mask_paths = ["/data/masks/slide_a_mask.tif", "/data/masks/slide_b_mask.tif"]
+        self.patch_size = (label_hw, label_hw)
+        self.reads = []
+
+    def __len__(self):
+        return int(self._cum_lengths[-1])
+
+    def labels(self, i):
+        rng = np.random.Generator(np.random.PCG64(1000 + i))
+        return (rng.random((1, *self.patch_size)) > 0.8).astype(np.uint8)
+
+    def __getitem__(self, i):
+        self.reads.append(int(i))
+        img = int(np.searchsorted(self._cum_lengths, i, side="right"))
+        li = i - (int(self._cum_lengths[img - 1]) if img else 0)
+        cols = int(self._sizes[img, 1])
+        return (torch.tensor([float(i)]), torch.from_numpy(self.labels(i)),
+                (img, np.asarray((li // cols, li % cols)), self.image_paths[img], self.mask_paths[img]))
+
+
+def _cpu_stitch(tiles, rc, grid):
+    th, tw = tiles.shape[1:]
+    for t, (r, c) in zip(tiles, rc.tolist()):
+        grid[r * th:(r + 1) * th, c * tw:(c + 1) * tw] = t.to(grid.dtype)
+    return grid
+
+
+def _run_driver(ws_label):
+    from vqae_amd.extract_embeddings import get_encodings
+    g = load_golden("driver")
+    tiles = torch.from_numpy(g["tiles"])
+    ds = _FixtureSlides(g["sizes"])
+    encode = lambda x: tiles[x.reshape(-1).long()]
+    pool = lambda lab, out: torch.nn.functional.adaptive_max_pool2d(lab.float().reshape(lab.shape[0], 1, *lab.shape[-2:]), out)[:, 0].to(torch.uint8)
+    got = dict(get_encodings(None, ds, batch_size=7, stitch_fn=_cpu_stitch, device="cpu", num_workers=0,
+                             encode_fn=encode, pool_fn=pool))
+    return g, ds, got
+
+
+def _check_driver(g, ds, got, oracle):
+    for name in ("images/slide_a", "images/slide_b"):
+        ref = g["grid:" + name]
+        assert got[name].dtype == ref.dtype and np.array_equal(got[name], ref), name
+    # masks: adaptive max-pool of every tile's label, stitched (oracle restatement of extract_embeddings.py:127-130,77-84)
+    first = 0
+    for s, name in enumerate(("masks/slide_a_mask", "masks/slide_b_mask")):
+        r, c = (int(v) for v in ds._sizes[s])
+        pooled = np.stack([oracle.adaptive_max_pool_labels(ds.labels(first + i)[0][None], 4)[0] for i in range(r * c)])
+        want = oracle.cast_to_lowest_dtype(oracle.stitch_slide(pooled.astype(np.int64), r, c))
+        assert got[name].dtype == want.dtype and np.array_equal(got[name], want), name
+        first += r * c
+
+
+def test_run_eval_get_encodings_single_process(amd, oracle):
+    g, ds, got = _run_driver(1)
+    _check_driver(g, ds, got, oracle)
+    assert sorted(ds.reads) == list(range(42))
+
+
+def _sharded_driver_worker(rank, ws, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        import vqae_amd  # noqa: F401
+        from oracle import vqae_oracle
+        g, ds, got = _run_driver(ws)
+        _check_driver(g, ds, got, vqae_oracle)
+        q.put((rank, True, sorted(ds.reads)))
+    except Exception as e:                                          # surface the failure in the parent
+        import traceback
+        q.put((rank, False, traceback.format_exc()))
+    dist.destroy_process_group()
+
+
+def test_sharded_run_eval_get_encodings_gloo_world2(amd):
+    """Two ranks, batches of 7 over 42 tiles of two interleaved slides: every rank assembles the reference's grids
+    (images and masks, incl. the bool cast), and each rank's loader READ only its own share of every batch."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29800 + os.getpid() % 150
+    procs = [ctx.Process(target=_sharded_driver_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert all(r[1] for r in res), [r[2] for r in res if not r[1]]
+    from vqae_amd.dist import shard_range
+    want = [[], []]
+    for b0 in range(0, 42, 7):
+        for r in range(2):
+            lo, hi = shard_range(7, r, 2)
+            want[r] += list(range(b0 + lo, b0 + hi))
+    assert res[0][2] == want[0] and res[1][2] == want[1]           # host loading is divided, not replicated
+    assert sorted(res[0][2] + res[1][2]) == list(range(42))
+
+
+def _ema_worker(rank, ws, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        from vqae_amd.layers.vq import fused_all_reduce_stats
+        g = torch.Generator().manual_seed(7)
+        counts = torch.randint(0, 50, (2, 32), generator=g).float()
+        dw = torch.randn(2, 32, 16, generator=g)
+        c, d = fused_all_reduce_stats(counts[rank].clone(), dw[rank].clone())
+        # reference: two separate all_reduce(SUM) (vq.py:57-58)
+        c2, d2 = counts[rank].clone(), dw[rank].clone()
+        dist.all_reduce(c2); dist.all_reduce(d2)
+        ok = bool(torch.equal(c, c2) and torch.equal(d, d2))
+        # the `ema` fixture (two training-mode steps of the reference, single process) with the rows of step 0 split
+        # over the two ranks: per-rank code statistics -> fused all-reduce -> EMA / Laplace step (vq.py:60-74)
+        from oracle import vqae_oracle as O
+        gf = load_golden("ema")
+        D, K = int(gf["D"]), int(gf["K"])
+        z0, embed = O.make_vq_case(D, K, 1024, seed=3, adversarial=False)
+        z = z0 * 1.7 + 0.3
+        e, ea, cs = O.init_ema(z, embed, embed.clone(), torch.zeros(K))
+        idx = torch.from_numpy(gf["idx0"].astype(np.int64))
+        lo, hi = (0, 512) if rank == 0 else (512, 1024)
+        n_k = torch.zeros(K).index_add_(0, idx[lo:hi], torch.ones(hi - lo))
+        dw_k = torch.zeros(K, D).index_add_(0, idx[lo:hi], z[lo:hi])
+        n_k, dw_k = fused_all_reduce_stats(n_k, dw_k)
+        cs = cs * 0.99 + (1 - 0.99) * n_k
+        ea = ea * 0.99 + (1 - 0.99) * dw_k
+        tot = cs.sum()
+        e_new = ea / ((cs + 1e-5) / (tot + K * 1e-5) * tot).unsqueeze(1)
+        ok = ok and np.allclose(e_new.numpy(), gf["embed0"], rtol=2e-6, atol=1e-6) and \
+            np.allclose(cs.numpy(), gf["cluster_size0"], rtol=2e-6, atol=1e-6)
+        q.put((rank, ok, float((c - counts.sum(0)).abs().max())))
+    except Exception:
+        import traceback
+        q.put((rank, False, traceback.format_exc()))
+    dist.destroy_process_group()
+
+
+def test_ema_fused_all_reduce_equals_reference_two_reduces_gloo_world2(amd):
+    """_update_ema's two all_reduce(SUM) calls ([K] and [K, D], vq.py:57-58) travel as ONE flat buffer in the mirror:
+    element-wise sums are unaffected by the fusion (same per-element reduction), checked under 2 ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29950 + os.getpid() % 40
+    procs = [ctx.Process(target=_ema_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert all(r[1] for r in res), res

@@ -16,7 +16,7 @@ def test_get_encodings_synthetic_slides(amd, oracle):
     p["encoder.vq_layers.0.embed"] = torch.from_numpy(g["embed"])
     nat = amd.NativeVQAE(amd.SPECS["tiny"], p)
     ds = SyntheticSlideDataset([(3, 2), (2, 3)], patch_size=32, raw=True, names=["a", "b"])
-    grids = dict(get_encodings(nat, ds, batch_size=5))             # batches straddle the two slides
+    grids = dict(get_encodings(nat, ds, batch_size=5, autocast_dtype=None, num_workers=0))   # fp32 convs; batches straddle the two slides
     assert set(grids) == {"images/a", "images/b", "masks/a_mask", "masks/b_mask"}
     # oracle: encode every tile on the CPU and stitch
     for s, name in enumerate(["a", "b"]):
@@ -37,7 +37,7 @@ def test_get_encodings_synthetic_slides(amd, oracle):
         wantm = oracle.cast_to_lowest_dtype(oracle.stitch_slide(np.stack(labs), rows, cols))
         assert np.array_equal(grids[f"masks/{name}_mask"], wantm) and grids[f"masks/{name}_mask"].dtype == wantm.dtype
     # reference yield contract of run_eval: ((idx, names, img_index, patch_index), (labels, ...))
-    first = next(iter(run_eval(nat, ds, batch_size=4)))
+    first = next(iter(run_eval(nat, ds, batch_size=4, num_workers=0)))
     (idx, names, ii, pi), (lab, lnames, _, _) = tuple(first)
     assert idx.dtype == torch.int64 and idx.shape == (4, 8, 8) and names[0] == "images/a" and lnames[0] == "masks/a_mask"
     assert pi.shape == (4, 2) and lab.shape == (4, 8, 8)
@@ -53,10 +53,10 @@ def test_module_mirror_works_with_driver(amd, oracle):
     model.load_state_dict(p, strict=False)
     model = model.cuda().eval()
     ds = SyntheticSlideDataset([(2, 2)], patch_size=32, raw=False)
-    grids = dict(get_encodings(model, ds, batch_size=3))
+    grids = dict(get_encodings(model, ds, batch_size=3, num_workers=0))
     nat = amd.NativeVQAE(amd.SPECS["tiny"], p)
     ds_raw = SyntheticSlideDataset([(2, 2)], patch_size=32, raw=True)
-    grids_raw = dict(get_encodings(nat, ds_raw, batch_size=3))
+    grids_raw = dict(get_encodings(nat, ds_raw, batch_size=3, num_workers=0))
     assert np.array_equal(grids["images/slide_000"], grids_raw["images/slide_000"])
 
 
@@ -70,8 +70,8 @@ def test_save_encodings_hdf5_streams_slide_grids(amd, oracle, tmp_path):
     p["encoder.vq_layers.0.embed"] = torch.from_numpy(g["embed"])
     nat = amd.NativeVQAE(amd.SPECS["tiny"], p)
     ds = SyntheticSlideDataset([(3, 2), (1, 4), (2, 2)], patch_size=32, raw=True, names=["normal_001", "tumor_002", "test_003"])
-    want = dict(get_encodings(nat, ds, batch_size=7))
-    out = save_encodings_hdf5(tmp_path / "direct.hdf5", nat, ds, batch_size=7)
+    want = dict(get_encodings(nat, ds, batch_size=7, num_workers=2))
+    out = save_encodings_hdf5(tmp_path / "direct.hdf5", nat, ds, batch_size=7, num_workers=2)
     r = hdf5.H5Reader(out)
     assert sorted(r.keys()) == ["images", "masks"]
     for key in ("normal_001", "tumor_002", "test_003"):
@@ -79,8 +79,47 @@ def test_save_encodings_hdf5_streams_slide_grids(amd, oracle, tmp_path):
         assert a.dtype == want["images/" + key].dtype and np.array_equal(a, want["images/" + key])
         assert m.dtype == want["masks/" + key + "_mask"].dtype and np.array_equal(m, want["masks/" + key + "_mask"])
     # the reference's two-step route (.npy per slide, then the converter) gives the same file content
-    save_encodings(tmp_path, nat, ds, batch_size=7)
+    save_encodings(tmp_path, nat, ds, batch_size=7, num_workers=2)
     two_step = hdf5.read_hdf5(convert_npy_to_hdf5(tmp_path / "encodings"))
     direct = hdf5.read_hdf5(out)
     assert all(np.array_equal(two_step[g_][n], direct[g_][n]) and two_step[g_][n].dtype == direct[g_][n].dtype
                for g_ in direct for n in direct[g_])
+
+
+def test_run_eval_default_is_the_reference_fp16_autocast(amd, oracle):
+    """run_eval's defaults are the reference's (extract_embeddings.py:92-101,124-125): batch 100, 6 workers,
+    prefetch 5 and the encoder under fp16 autocast.  With the defaults a NativeVQAE AND a module mirror produce the
+    codes of the reference under autocast(float16) (fixture model_tiny_f16, recorded from the imported reference);
+    autocast_dtype=None gives the fp32 codes (fixture model_tiny)."""
+    import inspect
+    from vqae_amd.extract_embeddings import run_eval
+    from vqae_amd.model import VQAE
+    sig = inspect.signature(run_eval).parameters
+    assert sig["batch_size"].default == 100 and sig["num_workers"].default == 6 and sig["prefetch_factor"].default == 5
+    assert sig["autocast_dtype"].default == torch.float16
+    g16, g32 = load_golden("model_tiny_f16"), load_golden("model_tiny")
+    p = oracle.make_params(oracle.SPECS["tiny"], 0)
+    p["encoder.vq_layers.0.embed"] = torch.from_numpy(g16["embed"])
+    x = oracle.make_patches(int(g16["batch"]), 32, 0)
+
+    class Patches(torch.utils.data.Dataset):                      # the fixture's two patches as a one-slide dataset
+        _sizes = np.array([[1, 2]]); _lengths = np.array([2]); _cum_lengths = np.array([2])
+        image_paths = ["/d/images/s.tif"]; mask_paths = ["/d/masks/s_mask.tif"]; patch_size = (32, 32)
+
+        def __len__(self):
+            return 2
+
+        def __getitem__(self, i):
+            return x[i], torch.zeros(1, 32, 32, dtype=torch.uint8), (0, np.asarray((0, i)), self.image_paths[0], self.mask_paths[0])
+
+    nat = amd.NativeVQAE(amd.SPECS["tiny"], p)
+    model = VQAE.from_spec(amd.SPECS["tiny"])
+    model.load_state_dict(p, strict=False)
+    model = model.cuda().eval()
+    for m in (nat, model):
+        (idx, *_), _ = tuple(next(iter(run_eval(m, Patches()))))              # all defaults (6 workers, fp16 autocast)
+        agree16 = float((idx.cpu().numpy() == g16["idx"].astype(np.int64)).mean())
+        (idx32, *_), _ = tuple(next(iter(run_eval(m, Patches(), autocast_dtype=None, num_workers=0))))
+        assert np.array_equal(idx32.cpu().numpy(), g32["idx"].astype(np.int64))
+        assert agree16 >= 0.99, agree16
+    assert nat.compute_dtype == 0 and nat.with_dtype(torch.float16).compute_dtype == 2

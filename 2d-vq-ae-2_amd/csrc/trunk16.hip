@@ -46,6 +46,17 @@ template <> struct E16<VQAE_DT_F16> {
     static __device__ __forceinline__ float rnd(float v) { return (float)(_Float16)v; }
 };
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter
+// (s_waitcnt vmcnt(0)): every global load in flight -- prefetched weight fragments, residual rows, the next tile's
+// input rows -- would have to land before each phase boundary.  These kernels exchange data between waves through
+// LDS only (each lane re-reads / overwrites its own global elements; t1' is consumed by the next launch), so the
+// barrier needs the LDS counter alone.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 struct T16K {
     const void* __restrict__ t1;     // [M][C] 16-bit: round16(ELU(round16(conv1) + b2a) + b2b), the conv2 operand
     const void* __restrict__ w2f;    // conv2 weights, fragment order [C/32][9 * C/16][64][8] 16-bit
@@ -57,13 +68,15 @@ struct T16K {
     float act_a, act_b, t_scale, t_b4, n_b1a, n_b1b, n_b2a, n_b2b;
 };
 
-template <int C, int W> struct T16Cfg {
+template <int C, int W, int MT> struct T16Cfg {
+    static_assert(MT == 2 || MT == 4, "m-tiles per workgroup");
     static_assert(W == 32 || W == 64 || W == 128, "grid width");
     static_assert(C == 64 || C == 128 || C == 256, "channels");
     static constexpr int NW = C / 32;                 // waves = 32-channel output slices
     static constexpr int NT = NW * 64;                // threads
     static constexpr int SEG = W / 32;                // 32-pixel segments per image row
-    static constexpr int R = 4 / SEG;                 // image rows per workgroup (4 m-tiles of 32 pixels = 128 pixels)
+    static constexpr int R = MT / SEG;                // image rows per workgroup (MT m-tiles of 32 pixels)
+    static_assert(MT % SEG == 0, "whole image rows per workgroup");
     static constexpr int PS = 2 * C + 16;             // LDS bytes per pixel: odd 16-B slot stride -> conflict-free b128 reads
     static constexpr int KS = C / 16;                 // k-slices per tap
     static constexpr int LDS_BYTES = (R + 2) * W * PS;
@@ -79,17 +92,17 @@ __device__ unsigned long long* g_t16_trace = nullptr;
 
 constexpr int NB_MAX = 8;                             // weight-fragment ring depth (k-steps in flight per wave): 8, or 6 at C = 64
 
-template <int C, int W, int DT, bool NEXT>
+template <int C, int W, int MT, int DT, bool NEXT>
 __global__ __launch_bounds__(C * 2, 2)
 void trunk16_kernel(const T16K p) {
-    using K = T16Cfg<C, W>;
+    using K = T16Cfg<C, W, MT>;
     using E = E16<DT>;
     using x8 = typename E::x8;
     using x4 = typename E::x4;
     constexpr int NT = K::NT, SEG = K::SEG, R = K::R, PS = K::PS, KS = K::KS;
     constexpr int NS2 = 9 * KS;
     constexpr int NB = (3 * KS) % NB_MAX == 0 ? NB_MAX : 6;
-    extern __shared__ __attribute__((aligned(16))) char lds[];      // A: [(R + 2) * W pixels][PS];  T: [128 pixels][PS] over it
+    extern __shared__ __attribute__((aligned(16))) char lds[];      // A: [(R + 2) * W pixels][PS];  T: [32 MT pixels][PS] over it
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -109,6 +122,12 @@ void trunk16_kernel(const T16K p) {
     const int64_t pix0 = ((int64_t)img * p.H + y0) * W;             // first output pixel of this tile (NHWC pixel index)
     STAMP(0);
 
+    // first ring of conv2 weight fragments (L2), requested ahead of the input rows
+    // ---- conv2: acc[mi] (32 channels x 32 pixels) += W2[tap] (row operand, from L2) x A[tap-shifted pixels] (LDS) --------
+    const char* const w2p = (const char*)p.w2f + ((int64_t)wave * NS2 * 64 + lane) * 16;
+    x8 wq[NB];
+#pragma unroll
+    for (int s = 0; s < NB; ++s) wq[s] = *reinterpret_cast<const x8*>(w2p + s * 1024);
     // ---- stage the R + 2 input rows (wrap-around halo) in LDS, 16-bit, once --------------------------------------------
     {
         constexpr int CPP = C * 2 / 16;                             // 16-byte chunks per pixel
@@ -134,40 +153,52 @@ void trunk16_kernel(const T16K p) {
         }
     }
 
-    // ---- conv2: acc[mi] (32 channels x 32 pixels) += W2[tap] (row operand, from L2) x A[tap-shifted pixels] (LDS) --------
-    const char* const w2p = (const char*)p.w2f + ((int64_t)wave * NS2 * 64 + lane) * 16;
-    x8 wq[NB];
-#pragma unroll
-    for (int s = 0; s < NB; ++s) wq[s] = *reinterpret_cast<const x8*>(w2p + s * 1024);
     int abase[SEG][3];                                              // byte offset of (segment, dx)'s pixel column + lane's k half
 #pragma unroll
     for (int sg = 0; sg < SEG; ++sg)
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) abase[sg][dx] = ((sg * 32 + x + dx - 1) & (W - 1)) * PS + 16 * h;
-    f32x16 acc[4];
+    f32x16 acc[MT];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
-    __syncthreads();
+    lds_barrier();
+    STAMP(1);
     static_assert((3 * KS) % NB == 0, "ring depth must divide a tap row's k-steps");
     // one tap row (dy) per trip of a real loop, its 3 * KS k-steps unrolled: keeps the scheduling window (and the
     // registers the compiler spends on hoisted LDS reads) bounded.  The ring runs NB steps ahead across trips; the
     // last trip's look-ahead reads NB KiB past this wave's fragments (the next n-tile's, or the buffer's tail pad).
     const char* wrow = w2p;
     const char* arow = lds;
+    // Software pipeline, pinned with sched_group_barrier (left alone, hipcc batches the ring's refills and waits for the
+    // first of them right after issuing it: one exposed L2 round trip per 8 k-steps): per k-step ONE weight-fragment
+    // load (for step s + NB), then 4 x { MFMA of step s, LDS fragment read of step s + 1 }.
+    auto load_a = [&](x8 (&dst)[MT], const char* base, int s) {
+        const int dx = s / KS, ks = s % KS;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+            const int row = mi / SEG, sg = mi % SEG;
+            dst[mi] = *reinterpret_cast<const x8*>(base + abase[sg][dx] + row * W * PS + ks * 32);
+        }
+    };
+    x8 af[2][MT];
+    load_a(af[0], arow, 0);
 #pragma unroll 1
     for (int dy = 0; dy < 3; ++dy) {
 #pragma unroll
         for (int s = 0; s < 3 * KS; ++s) {
-            const int dx = s / KS, ks = s % KS;
             const x8 wc = wq[s % NB];
             wq[s % NB] = *reinterpret_cast<const x8*>(wrow + (s + NB) * 1024);
+            if (s + 1 < 3 * KS) load_a(af[(s + 1) & 1], arow, s + 1);
+            else if (dy < 2) load_a(af[0], arow + W * PS, 0);       // 3 * KS is even: the next tap row starts in af[0]
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const int row = mi / SEG, sg = mi % SEG;
-                const x8 a = *reinterpret_cast<const x8*>(arow + abase[sg][dx] + row * W * PS + ks * 32);
-                acc[mi] = E::mma(wc, a, acc[mi]);
+            for (int mi = 0; mi < MT; ++mi) acc[mi] = E::mma(wc, af[s & 1][mi], acc[mi]);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
             }
         }
         wrow += 3 * KS * 1024;
@@ -180,33 +211,49 @@ void trunk16_kernel(const T16K p) {
     auto to_T = [&](const f32x4& v, int mi, int q) {                // 4 consecutive channels of one pixel -> T, 16-bit
         *reinterpret_cast<x4*>(lds + (mi * 32 + x) * PS + (cbase + 8 * q) * 2) = __builtin_convertvector(v, x4);
     };
-    auto gemm1x1 = [&](const void* wf) {                            // acc = Wf (C x C, row operand) x T (K = C)
+    // 1x1 tails: acc = Wf (C x C, row operand, fragments through the ring w1) x T (K = C).  The ring is filled by
+    // w_prefetch well ahead of its gemm (before the barrier / activation work in front of it).
+    constexpr int NR = KS < NB ? KS : NB;
+    x8 w1[NR];
+    auto w_prefetch = [&](const void* wf) -> const char* {
         const char* const wp = (const char*)wf + ((int64_t)wave * KS * 64 + lane) * 16;
-        constexpr int NR = KS < NB ? KS : NB;
-        x8 w[NR];
 #pragma unroll
-        for (int s = 0; s < NR; ++s) w[s] = *reinterpret_cast<const x8*>(wp + s * 1024);
+        for (int s = 0; s < NR; ++s) w1[s] = *reinterpret_cast<const x8*>(wp + s * 1024);
+        return wp;
+    };
+    auto gemm1x1 = [&](const char* wp) {
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
-        __syncthreads();                                            // T complete
+        lds_barrier();                                            // T complete
+        auto load_b = [&](x8 (&dst)[MT], int s) {
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) dst[mi] = *reinterpret_cast<const x8*>(lds + (mi * 32 + x) * PS + 16 * h + s * 32);
+        };
+        x8 bf[2][MT];
+        load_b(bf[0], 0);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const x8 wc = w[s % NR];
-            if (s + NR < KS) w[s % NR] = *reinterpret_cast<const x8*>(wp + (s + NR) * 1024);
+            const x8 wc = w1[s % NR];
+            if (s + NR < KS) w1[s % NR] = *reinterpret_cast<const x8*>(wp + (s + NR) * 1024);
+            if (s + 1 < KS) load_b(bf[(s + 1) & 1], s + 1);
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const x8 b = *reinterpret_cast<const x8*>(lds + (mi * 32 + x) * PS + 16 * h + s * 32);
-                acc[mi] = E::mma(wc, b, acc[mi]);
+            for (int mi = 0; mi < MT; ++mi) acc[mi] = E::mma(wc, bf[s & 1][mi], acc[mi]);
+            if (s + NR < KS) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (s + 1 < KS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
         }
     };
 
     // ---- t2 = round(ELU(round(conv2) + b3a) + b3b) -> T (over the dead input rows) ------------------------------------
-    __syncthreads();                                                // every wave is done reading A
+    const char* const wp3 = w_prefetch(p.w3f);                      // in flight across the barrier and the activation work
+    lds_barrier();                                                // every wave is done reading A
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 v;
@@ -217,20 +264,21 @@ void trunk16_kernel(const T16K p) {
 
     // residual rows: requested now, consumed after conv3 (16 B per lane: 4 consecutive channels of one pixel)
     float* const xrow = p.xio + (pix0 + x) * C + cbase;
-    f32x4 xr[4][4];
+    f32x4 xr[MT][4];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
         for (int q = 0; q < 4; ++q) xr[mi][q] = *reinterpret_cast<const f32x4*>(xrow + (int64_t)mi * 32 * C + 8 * q);
 
     STAMP(3);
-    gemm1x1(p.w3f);                                                 // conv3
+    gemm1x1(wp3);                                                   // conv3
     STAMP(4);
+    const char* wp1 = nullptr;
+    if (NEXT) wp1 = w_prefetch(p.w1nf);
 
     // ---- out = round(conv3) * scale + bias4 + x, in place; u = round(ELU(out + b1a') + b1b') for the next conv1 --------
-    if (NEXT) __syncthreads();                                      // conv3 finished reading T
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    if (NEXT) lds_barrier();                                      // conv3 finished reading T
+    auto finish = [&](int mi, const f32x4 (&xv)[4]) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 t, u;
@@ -238,20 +286,23 @@ void trunk16_kernel(const T16K p) {
             for (int e = 0; e < 4; ++e) {
                 float v = E::rnd(acc[mi][4 * q + e]) * p.t_scale;
                 v = v + p.t_b4;
-                v = v + xr[mi][q][e];
+                v = v + xv[q][e];
                 t[e] = v;
                 u[e] = elu_act(v + p.n_b1a) + p.n_b1b;
             }
             *reinterpret_cast<f32x4*>(xrow + (int64_t)mi * 32 * C + 8 * q) = t;
             if (NEXT) to_T(u, mi, q);
         }
+    };
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) finish(mi, xr[mi]);
     STAMP(5);
     if constexpr (NEXT) {
-        gemm1x1(p.w1nf);                                            // the next block's conv1
+        gemm1x1(wp1);                                               // the next block's conv1
         STAMP(6);
         typename E::elem* const trow = (typename E::elem*)p.t1n + (pix0 + x) * C + cbase;
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f32x4 v;
@@ -263,6 +314,7 @@ void trunk16_kernel(const T16K p) {
     STAMP(7);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
 // packed fp32 [C n][taps * C] (tap-major K, vqae_conv_pack_weight_f32; already rounded to the 16-bit type) ->
 // fragment order [C/32 n-tiles][taps * C/16 k-steps][64 lanes][8]: lane (r, h) of k-step (tap, ks) holds
 // w[n = 32 nt + r][tap][k = 16 ks + 8 h + j], j = 0..7 -- the MFMA row-operand fragment of that step.
@@ -288,31 +340,33 @@ __global__ void round_pack16_kernel(const float* __restrict__ src, EL* __restric
     reinterpret_cast<el4*>(dst)[i] = __builtin_convertvector(v, el4);
 }
 
-template <int C, int W, int DT>
-int launch_t16(const T16K& k, bool next, int n_tiles, hipStream_t stream) {
-    using K = T16Cfg<C, W>;
+template <int C, int W, int MT, int DT>
+int launch_t16(const T16K& k, bool next, int64_t n_px, hipStream_t stream) {
+    using K = T16Cfg<C, W, MT>;
     static bool attr_set = false;
     if (!attr_set) {
-        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)trunk16_kernel<C, W, DT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES));
-        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)trunk16_kernel<C, W, DT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES));
+        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)trunk16_kernel<C, W, MT, DT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES));
+        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)trunk16_kernel<C, W, MT, DT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES));
         attr_set = true;
     }
-    const double m = (double)n_tiles * 128.0;
-    vqae::ProfScope prof(C >= 128 && W == 32 ? vqae::PROF_CONV3X3_TRUNK : 0, stream, 2.0 * m * C * (9.0 * C + C + (next ? C : 0)));
-    if (next) trunk16_kernel<C, W, DT, true><<<n_tiles, K::NT, K::LDS_BYTES, stream>>>(k);
-    else trunk16_kernel<C, W, DT, false><<<n_tiles, K::NT, K::LDS_BYTES, stream>>>(k);
+    const int n_tiles = (int)(n_px / (32 * MT));
+    vqae::ProfScope prof(C >= 128 && W == 32 ? vqae::PROF_CONV3X3_TRUNK : 0, stream, 2.0 * (double)n_px * C * (9.0 * C + C + (next ? C : 0)));
+    if (next) trunk16_kernel<C, W, MT, DT, true><<<n_tiles, K::NT, K::LDS_BYTES, stream>>>(k);
+    else trunk16_kernel<C, W, MT, DT, false><<<n_tiles, K::NT, K::LDS_BYTES, stream>>>(k);
     prof.done();
     VQAE_LAUNCH_CHECK();
     return VQAE_OK;
 }
 
 template <int DT>
-int launch_t16_cw(const T16K& k, bool next, int c, int w, int n_tiles, hipStream_t stream) {
-    if (c == 128 && w == 32) return launch_t16<128, 32, DT>(k, next, n_tiles, stream);
-    if (c == 256 && w == 32) return launch_t16<256, 32, DT>(k, next, n_tiles, stream);
-    if (c == 64 && w == 64) return launch_t16<64, 64, DT>(k, next, n_tiles, stream);
-    if (c == 128 && w == 64) return launch_t16<128, 64, DT>(k, next, n_tiles, stream);
-    if (c == 64 && w == 128) return launch_t16<64, 128, DT>(k, next, n_tiles, stream);
+int launch_t16_cw(const T16K& k, bool next, int c, int w, int64_t n_px, hipStream_t stream) {
+    // 4 m-tiles (128 pixels) per workgroup everywhere.  2 m-tiles (twice the resident workgroups) measured slower at
+    // C = 128: every weight fragment then feeds 2 MFMAs instead of 4 and the kernel becomes bound by the L1 address path.
+    if (c == 128 && w == 32) return launch_t16<128, 32, 4, DT>(k, next, n_px, stream);
+    if (c == 256 && w == 32) return launch_t16<256, 32, 4, DT>(k, next, n_px, stream);
+    if (c == 64 && w == 64) return launch_t16<64, 64, 4, DT>(k, next, n_px, stream);
+    if (c == 128 && w == 64) return launch_t16<128, 64, 4, DT>(k, next, n_px, stream);
+    if (c == 64 && w == 128) return launch_t16<64, 128, 4, DT>(k, next, n_px, stream);
     return vqae::fail(VQAE_ERR_UNSUPPORTED, "trunk16: C = %d on a %d-wide grid", c, w);
 }
 
@@ -365,9 +419,8 @@ int trunk16_block(const void* t1, const void* w2f, const void* w3f, float act_a,
     k.t1 = t1; k.w2f = w2f; k.w3f = w3f; k.w1nf = w1nf; k.xio = xio; k.t1n = t1_next; k.H = h;
     k.act_a = act_a; k.act_b = act_b; k.t_scale = t_scale; k.t_b4 = t_b4;
     k.n_b1a = n_b1a; k.n_b1b = n_b1b; k.n_b2a = n_b2a; k.n_b2b = n_b2b;
-    const int n_tiles = (int)(M / 128);
-    if (dtype == VQAE_DT_BF16) return launch_t16_cw<VQAE_DT_BF16>(k, w1nf != nullptr, c, w, n_tiles, stream);
-    return launch_t16_cw<VQAE_DT_F16>(k, w1nf != nullptr, c, w, n_tiles, stream);
+    if (dtype == VQAE_DT_BF16) return launch_t16_cw<VQAE_DT_BF16>(k, w1nf != nullptr, c, w, M, stream);
+    return launch_t16_cw<VQAE_DT_F16>(k, w1nf != nullptr, c, w, M, stream);
 }
 
 }  // namespace vqae

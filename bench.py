@@ -25,7 +25,11 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak (= fp32 vector peak)
+PEAK_16BIT_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 / fp16 matrix peak
 PEAK_HBM_GBS = 8000.0
+
+# BASELINE.json `configs` that a (--config, --dtype, --batch, --mode) combination reproduces on one GPU
+BASELINE_CONFIGS = {("B", "f32", 256, "full"): 1, ("A", "bf16", 256, "full"): 2, ("C", "f16", 256, "full"): 3}
 
 
 def host_cores():
@@ -44,14 +48,27 @@ def log(msg):
 T0 = time.perf_counter()
 
 
-def pmc_traffic(kernel_class):
-    """HBM bytes per launch of the dominant kernel from the separate rocprofv3 --pmc passes (FETCH_SIZE
-    doubled per MI355X_MICROARCH.md, + WRITE_SIZE), as summarised in profiles/r01_pmc_traffic.json."""
+def kernel_source_hash(files):
+    """sha256 over the HIP sources of the dominant kernel: PMC traffic figures are only valid for the code they were
+    measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in files:
+        h.update(open(os.path.join(ROOT, "2d-vq-ae-2_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(key):
+    """HBM bytes per launch of the dominant kernel from separate rocprofv3 --pmc passes (FETCH_SIZE doubled per
+    MI355X_MICROARCH.md, + WRITE_SIZE), as recorded in profiles/r02_pmc_traffic.json by tools/pmc_traffic.sh.  Each
+    entry carries the hash of the kernel sources it was measured on; a figure for other code is refused (null)."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        return d.get(f"class{kernel_class}_bytes_per_launch")
-    except Exception:
-        return None
+        d = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))[key]
+        if d["source_hash"] != kernel_source_hash(d["sources"]):
+            return None, f"stale: measured on sources {d['source_hash']}, kernel has changed since"
+        return d["bytes_per_launch"], f"rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, sources {d['source_hash']}"
+    except Exception as e:                      # no profile for this configuration
+        return None, f"not measured ({type(e).__name__})"
 
 
 def synth_patches_u8(batch, size, batch_no, device):
@@ -112,8 +129,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start one fresh process per GPU through torch.distributed.run as children
+        # (nothing has touched the GPU in this process) and leave with their exit code
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or "RANK" in os.environ          # under torchrun even a single rank goes through RCCL
@@ -188,23 +213,44 @@ def main():
         if rank == 0:          # the gathered grids hold every rank's tiles in rank order
             assert torch.equal(gathered[:B], idx)
 
+    # ---- the same steps with the batch coming from pinned host memory each step (PCIe-inclusive rate; never `value`) ----
+    h2d_value = None
+    if rank == 0 and world == 1:
+        host = x.cpu().pin_memory()
+        xd = torch.empty_like(x)
+        n_h2d = max(2, min(args.steps, 5))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n_h2d):
+            xd.copy_(host, non_blocking=True)
+            if args.mode == "full":
+                nat.forward(xd, "NCHW", idx_dtype=idx_dtype)
+            else:
+                nat.encode(xd, "NCHW", idx_dtype=idx_dtype, want_q=False)
+        torch.cuda.synchronize()
+        h2d_value = B * n_h2d / (time.perf_counter() - t1)
+
     if rank == 0:
         total_patches = world * B * args.steps
         value = total_patches / dt
         flops_patch = nat.flops_per_patch(size, size, True, args.mode == "full")
+        bidx = BASELINE_CONFIGS.get((args.config, args.dtype, B, args.mode))
+        what = (f"BASELINE configs[{bidx}]" if bidx is not None else "variant (not a BASELINE.json config)")
+        in_dt = "fp32" if args.dtype == "f32" else f"fp32 patches, {args.dtype} autocast convolutions"
         res = {
             "metric": "patches/sec (VQAE.forward: encoder -> VQ -> decoder)" if args.mode == "full"
                       else "patches/sec (Encoder.forward: encoder -> VQ indices)",
             "value": round(value, 2), "unit": "patches/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1] (cfg {args.config}): batch {B}/GPU of {size}x{size}x3 fp32 "
-                                   f"patches -> {zh}x{zh} codes, K={spec.num_embeddings}, D={spec.code_dim}, "
+            "config": {"workload": f"{what} (cfg {args.config}): batch {B}/GPU of {size}x{size}x3 {in_dt} "
+                                   f"-> {zh}x{zh} codes, K={spec.num_embeddings}, D={spec.code_dim}, "
                                    f"{args.mode} forward", "global_batch": world * B,
                        "parallelism": f"patch-sharded x{world}" + (", all-gather of code grids" if world > 1 else "")},
             "conv_tflops_direct_equivalent": round(value * flops_patch / 1e12, 2),
             "recon_mse_vs_input": float(((out - x) ** 2).mean()) if out is not None else None,
             "vq_loss": float(loss),
+            "value_with_h2d": round(h2d_value, 2) if h2d_value else None,
         }
         # ---- roofline of the dominant kernel ---------------------------------------------------
         if prof_on and k_n.value > 0:
@@ -212,20 +258,38 @@ def main():
             C = spec.channels
             M = B * zh * zh
             alg = k_work.value / k_n.value                  # algorithmic work per launch, summed by the library
-            if args.prof_class == 1:
-                # trunk Fixup block kernel (csrc/conv_wino.hip when fp32 / C = 128 / 32-wide grid, else conv_mfma.hip
-                # TAIL): conv2 3x3 circular + fused conv3 and next-block conv1 tails, M = B*32*32 pixels per launch.
-                #   direct form:   2*M*128*(1152 + 128 + 128) flop
-                #   Winograd form: 2*M*128*( 512 + 128 + 128) flop EXECUTED on the matrix pipe (F(2x2,3x3): 16 multiplies
-                #                  per 4 outputs) -- `achieved`/`frac` price the executed MFMA work, i.e. real pipe
-                #                  utilisation; `direct_equivalent_tflops` is the same launch priced as a direct conv.
+            if args.prof_class == 1 and args.dtype == "f32":
+                # fp32 trunk Fixup block kernel (csrc/conv_wino.hip at C = 128 / 32-wide grid, else conv_mfma.hip TAIL):
+                # conv2 3x3 circular + fused conv3 and next-block conv1 tails, M = B*32*32 pixels per launch.
+                #   direct form:   2*M*C*(9C + C + C) flop
+                #   Winograd form: 2*M*C*(4C + C + C) flop EXECUTED on the matrix pipe (F(2x2,3x3): 16 multiplies per 4
+                #                  outputs) -- `achieved`/`frac` price the executed MFMA work, i.e. real pipe utilisation;
+                #                  `direct_equivalent_*` price the same launch as a direct conv (may exceed 1.0 of peak).
                 direct = 2.0 * M * C * (9 * C + C + C)
-                res["roofline"] = {"kernel": "trunk Fixup block: conv2 3x3 (Winograd F(2x2,3x3) in fp32 at C=128) + fused "
-                                             "conv3 / next-conv1 tails",
+                wino = C in (128, 64, 32) and not os.environ.get("VQAE_NO_WINOGRAD")
+                traffic, tnote = pmc_traffic(f"{args.config}_{args.dtype}_B{B}")
+                res["roofline"] = {"kernel": "wino_trunk_kernel: trunk Fixup block, conv2 3x3 as Winograd F(2x2,3x3) + fused conv3 / "
+                                             "next-conv1 tails" if wino else "conv_mfma_kernel TAIL: trunk Fixup block, direct conv2 + fused tails",
                                    "bound": "mfma", "achieved": round(alg / (avg_ms * 1e-3) / 1e12, 2),
-                                   "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "traffic": pmc_traffic(1),
+                                   "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "traffic": traffic, "traffic_note": tnote,
                                    "launches": k_n.value, "avg_ms": round(avg_ms, 4), "alg_flops_per_launch": alg,
-                                   "direct_equivalent_tflops": round(direct / (avg_ms * 1e-3) / 1e12, 2)}
+                                   "winograd": bool(wino), "direct_equivalent_tflops": round(direct / (avg_ms * 1e-3) / 1e12, 2),
+                                   "direct_equivalent_frac": round(direct / (avg_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+            elif args.prof_class == 1:
+                # 16-bit trunk Fixup block kernel (csrc/trunk16.hip): direct conv2 on v_mfma_f32_32x32x16_{bf16,f16} + fused
+                # conv3 / next-conv1; algorithmic = executed flops 2*M*C*(9C + C + C); algorithmic HBM bytes per launch
+                # M*C*(2 [t1 in] + 4 + 4 [x in/out] + 2 [t1' out]) -- reported as hbm_* beside the MFMA fraction: the
+                # kernel sits between the two roofs.
+                traffic, tnote = pmc_traffic(f"{args.config}_{args.dtype}_B{B}")
+                hbm_bytes = M * C * 12.0
+                res["roofline"] = {"kernel": "trunk16_kernel: trunk Fixup block, direct conv2 3x3 + fused conv3 / next-conv1, "
+                                             f"{args.dtype} MFMA, 16-bit t1 in HBM",
+                                   "bound": "mfma", "achieved": round(alg / (avg_ms * 1e-3) / 1e12, 2),
+                                   "peak": PEAK_16BIT_MFMA_TFLOPS, "unit": "TFLOP/s", "traffic": traffic, "traffic_note": tnote,
+                                   "launches": k_n.value, "avg_ms": round(avg_ms, 4), "alg_flops_per_launch": alg,
+                                   "alg_hbm_bytes_per_launch": hbm_bytes,
+                                   "hbm_achieved_gbs": round(hbm_bytes / (avg_ms * 1e-3) / 1e9, 1),
+                                   "hbm_frac": round(hbm_bytes / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
             elif args.prof_class == 2:
                 res["roofline"] = {"kernel": "fixup_conv1_kernel<128> (stand-alone 1x1 conv1 at the head of a block chain; the "
                                              "other 1x1 convs run inside the fused trunk kernel)", "bound": "mfma",

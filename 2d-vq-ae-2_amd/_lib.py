@@ -68,6 +68,9 @@ SYMBOLS = {
     "vqae_vq_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "vqae_vq_forward_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_int, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vqae_vq_projected_workspace_bytes": (c_size_t, [c_int64]),
+    "vqae_vq_projected_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
+                                      c_float, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vqae_embed_code_f32": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "vqae_vq_code_stats_f32": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "vqae_vq_ema_update_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float,

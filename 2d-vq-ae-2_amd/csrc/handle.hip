@@ -128,6 +128,8 @@ struct vqae_handle {
     float *stem_w = nullptr, *stem_b = nullptr, *ostem_w = nullptr, *ostem_b = nullptr;
     float *embed = nullptr;
     float *pin_w = nullptr, *pin_b = nullptr, *pout_w = nullptr, *pout_b = nullptr;
+    float *pin_wt = nullptr, *pout_wr = nullptr;   // fused projected VQ (vq_proj.hip): proj_in transposed [C][8], proj_out [C][8], rounded
+    bool fuse_vq = true;                   // projection_dim == 8: proj_in + argmin + proj_out in one launch
     std::vector<void*> owned;              // every hipMalloc of the weight set
     // workspace
     float* buf[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -591,7 +593,8 @@ int ensure_workspace(vqae_handle* h, int B, int in_h, int in_w) {
     int rc = ensure_bufs(h, max_floats_per_patch(h, in_h, in_w) * (size_t)(B > 0 ? B : 1));
     if (rc) return rc;
     const int64_t rows = (int64_t)B * (in_h >> h->cfg.n_down) * (in_w >> h->cfg.n_down);
-    const size_t vq_need = vqae_vq_workspace_bytes(rows, h->K, h->D);
+    size_t vq_need = vqae_vq_workspace_bytes(rows, h->K, h->D);
+    if (h->D == 8) vq_need = std::max(vq_need, vqae_vq_projected_workspace_bytes(rows));
     if (vq_need > h->vq_ws_bytes) {
         VQAE_HIP_CHECK(hipDeviceSynchronize());
         if (h->vq_ws) (void)hipFree(h->vq_ws);
@@ -661,6 +664,14 @@ int run_encoder_convs(vqae_handle* h, const void* x, int x_kind, int B, int in_h
 int run_vq(vqae_handle* h, int B, int zh, int zw, void* idx, int idx_dtype, float* loss, hipStream_t st) {
     const int64_t rows = (int64_t)B * zh * zw;
     int rc;
+    if (h->cfg.projection_dim == 8 && h->fuse_vq && h->pin_wt) {
+        // reference default: the whole ProjectedEMAVectorQuantizer2d.forward in one pass over z (vq_proj.hip)
+        if ((rc = vqae_vq_projected_f32(h->buf[0], h->pin_wt, h->pin_b, h->embed, h->pout_wr, h->pout_b, rows, h->C, h->D, h->K,
+                                        h->cfg.commitment_cost, g_dt, idx, idx_dtype, h->buf[1], nullptr, loss, nullptr,
+                                        h->vq_ws, st))) return rc;
+        std::swap(h->buf[0], h->buf[1]);
+        return VQAE_OK;
+    }
     if (h->cfg.projection_dim > 0) {
         ConvCall pin(B, zh, zw, h->C, h->D, 1, 1, 0, VQAE_PAD_NONE);
         if ((rc = vqae_conv2d_f32(&pin.a, h->buf[0], h->pin_w, h->pin_b, nullptr, h->buf[1], st))) return rc;
@@ -724,6 +735,7 @@ extern "C" int vqae_create(const vqae_config* cfg, const vqae_tensor* tensors, i
     h->use_wino = !(getenv("VQAE_NO_WINOGRAD") && atoi(getenv("VQAE_NO_WINOGRAD")));
     h->fuse_up_tail = !(getenv("VQAE_NO_UP_TAIL_FUSION") && atoi(getenv("VQAE_NO_UP_TAIL_FUSION")));
     h->fuse_down = !(getenv("VQAE_NO_DOWN_FUSION") && atoi(getenv("VQAE_NO_DOWN_FUSION")));
+    h->fuse_vq = !(getenv("VQAE_NO_VQ_FUSION") && atoi(getenv("VQAE_NO_VQ_FUSION")));
     h->C = cfg->stem << cfg->n_down;
     h->D = cfg->projection_dim > 0 ? cfg->projection_dim : h->C;
     h->K = cfg->num_embeddings;
@@ -776,6 +788,15 @@ extern "C" int vqae_create(const vqae_config* cfg, const vqae_tensor* tensors, i
             if ((rc = find(tm, vq + "proj_out.weight", (int64_t)h->C * h->D, &p)) || (rc = upload_packed(h, p, h->C, h->D, 1, &h->pout_w))) return bail(rc);
             if ((rc = find(tm, vq + "proj_out.bias", h->C, &p)) || (rc = upload(h, p, h->C, &h->pout_b))) return bail(rc);
             if ((rc = vqae_round_inplace_f32(h->pout_b, h->C, cfg->compute_dtype, nullptr))) return bail(rc);
+            if (h->D == 8) {                                   // operands of the fused kernel: plain [C][8] matrices, rounded like conv weights
+                std::vector<float> wt((size_t)h->C * 8);
+                const float* pi = tm.at(vq + "proj_in.weight")->data;      // [8][C]
+                for (int j = 0; j < 8; ++j) for (int cc = 0; cc < h->C; ++cc) wt[(size_t)cc * 8 + j] = pi[(size_t)j * h->C + cc];
+                if ((rc = upload(h, wt.data(), (int64_t)h->C * 8, &h->pin_wt)) ||
+                    (rc = upload(h, tm.at(vq + "proj_out.weight")->data, (int64_t)h->C * 8, &h->pout_wr))) return bail(rc);
+                if ((rc = vqae_round_inplace_f32(h->pin_wt, (int64_t)h->C * 8, cfg->compute_dtype, nullptr)) ||
+                    (rc = vqae_round_inplace_f32(h->pout_wr, (int64_t)h->C * 8, cfg->compute_dtype, nullptr))) return bail(rc);
+            }
         }
     }
     if (has_dec) {

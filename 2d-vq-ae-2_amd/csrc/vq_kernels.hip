@@ -362,6 +362,41 @@ inline VqWorkspace carve(void* ws, int64_t N, int K, int D) {
 
 }  // namespace
 
+namespace vqae {
+// shared with the fused projected quantiser (vq_proj.hip)
+int vq_tier2_run(const float* z, const float* embed, int K, int D, int* idx32, const int* flag_count, const int* flag_list,
+                 hipStream_t stream) {
+    vq_tier2_kernel<<<256, 256, 0, stream>>>(z, embed, K, D, idx32, flag_count, flag_list);
+    VQAE_LAUNCH_CHECK();
+    return VQAE_OK;
+}
+
+// *loss = commitment * mean((z - embed[idx])^2) (vq.py:143); partials: >= 1024 doubles of scratch
+int vq_loss_from_idx(const float* z, const float* embed, const int* idx32, int64_t N, int D, float commitment, double* partials,
+                     float* loss, hipStream_t stream) {
+    const int64_t total4 = N * (D / 4);
+    const int nblk = (int)std::min<int64_t>(1024, ceil_div(total4, 256));
+    vq_gather_kernel<<<nblk, 256, 0, stream>>>((const float4*)z, (const float4*)embed, idx32, total4, D / 4, (float4*)nullptr, partials);
+    VQAE_LAUNCH_CHECK();
+    vq_finalize_loss_kernel<<<1, 256, 0, stream>>>(partials, nblk, 1.0 / ((double)N * (double)D), commitment, loss);
+    VQAE_LAUNCH_CHECK();
+    return VQAE_OK;
+}
+
+int vq_write_idx(const int* idx32, int64_t N, void* idx_out, int idx_dtype, hipStream_t stream) {
+    const unsigned gi = (unsigned)ceil_div(N, 256);
+    switch (idx_dtype) {
+        case VQAE_IDX_I64: vq_write_idx_kernel<int64_t><<<gi, 256, 0, stream>>>(idx32, N, (int64_t*)idx_out); break;
+        case VQAE_IDX_U8: vq_write_idx_kernel<uint8_t><<<gi, 256, 0, stream>>>(idx32, N, (uint8_t*)idx_out); break;
+        case VQAE_IDX_U16: vq_write_idx_kernel<uint16_t><<<gi, 256, 0, stream>>>(idx32, N, (uint16_t*)idx_out); break;
+        case VQAE_IDX_I32: vq_write_idx_kernel<int32_t><<<gi, 256, 0, stream>>>(idx32, N, (int32_t*)idx_out); break;
+        default: return fail(VQAE_ERR_INVALID, "vq: bad idx_dtype %d", idx_dtype);
+    }
+    VQAE_LAUNCH_CHECK();
+    return VQAE_OK;
+}
+}  // namespace vqae
+
 extern "C" size_t vqae_vq_workspace_bytes(int64_t n_rows, int n_codes, int dim) {
     const int64_t Kpad = vqae::round_up(n_codes, VQ_TK);
     return (size_t)(256 + 1024 * sizeof(double) + vqae::round_up((int64_t)dim * Kpad * 4, 256) +
@@ -424,16 +459,7 @@ extern "C" int vqae_vq_forward_f32(const float* z, const float* embed, int64_t N
             VQAE_LAUNCH_CHECK();
         }
     }
-    const unsigned gi = (unsigned)vqae::ceil_div(N, 256);
-    switch (idx_dtype) {
-        case VQAE_IDX_I64: vq_write_idx_kernel<int64_t><<<gi, 256, 0, stream>>>(w.idx32, N, (int64_t*)idx_out); break;
-        case VQAE_IDX_U8: vq_write_idx_kernel<uint8_t><<<gi, 256, 0, stream>>>(w.idx32, N, (uint8_t*)idx_out); break;
-        case VQAE_IDX_U16: vq_write_idx_kernel<uint16_t><<<gi, 256, 0, stream>>>(w.idx32, N, (uint16_t*)idx_out); break;
-        case VQAE_IDX_I32: vq_write_idx_kernel<int32_t><<<gi, 256, 0, stream>>>(w.idx32, N, (int32_t*)idx_out); break;
-        default: return vqae::fail(VQAE_ERR_INVALID, "vq_forward: bad idx_dtype %d", idx_dtype);
-    }
-    VQAE_LAUNCH_CHECK();
-    return VQAE_OK;
+    return vqae::vq_write_idx(w.idx32, N, idx_out, idx_dtype, stream);
 }
 
 extern "C" int vqae_embed_code_f32(const void* idx, int idx_dtype, const float* embed, int64_t N, int K, int D,

@@ -1,0 +1,263 @@
+// Fused projected vector quantiser for the reference's default codebook (projection_dim = 8):
+//   ProjectedEMAVectorQuantizer2d.forward = proj_out(VQ(proj_in(x)))            (vq_ae/layers/vq.py:190-192)
+//     z   = proj_in(x)                       1x1 conv C -> 8 with bias          (vq.py:178-182)
+//     idx = argmin_k (sum_j |z_j - e_kj|^4)^(1/4), lowest k on ties             (vq.py:121-129, p = inputs.dim() = 4)
+//     q   = z + (e[idx] - z)                 straight-through forward value     (vq.py:130,146)
+//     out = proj_out(q)                      1x1 conv 8 -> C with bias          (vq.py:183-187)
+//     loss = beta * mean((z - e[idx])^2)     in the 8-D space                   (vq.py:143)
+// in ONE pass over the activation: a row of x (C fp32 channels) is read once, its 8-D projection never leaves registers
+// for the distance loop, and the C-channel output row is written once -- this is the one configuration where the
+// lookup's algorithmic HBM traffic (2 C * 4 B per row) is comparable to its arithmetic.
+//
+// Work split: ONE ROW PER LANE.  Everything a lane needs besides its own row is wave-uniform -- proj_in / proj_out
+// weights, biases, the 8-float codebook rows (17 KB in all at K = 256, C = 128) -- and is staged once per workgroup in
+// LDS, from where every lane reads the SAME address (a broadcast read: no bank conflicts, no cross-lane traffic):
+// z_j += x_c * Wt_in[c][j];  d = z_j - e_kj;  out_c += q_j * W_out[c][j].  (Through the scalar cache instead -- SGPR
+// operands -- the kernel ran at 0.9 TB/s: s_load results return out of order, so every group of scalar loads cost a
+// full lgkmcnt(0) round trip that 4 waves per SIMD could not cover.)
+// Per (row, code): 8 sub + 8 mul + 8 fma in channel order (the tier-1 recipe of vq_kernels.hip) + 5 to keep
+// (best, second best, argmin).  Rows whose best/second gap lies inside the evaluation noise are flagged and re-evaluated
+// bit-faithfully by vq_tier2_kernel on the stored 8-D z (32 B per row); their output rows are then patched.
+//
+// 16-bit autocast modes (DT): proj_in / proj_out are convolutions, so their operands and results are rounded to the
+// 16-bit type exactly as vqae_conv2d_f32 does (weights / biases arrive pre-rounded); the distance, q and the loss stay fp32.
+#include "common.h"
+
+namespace vqae {
+int vq_tier2_run(const float* z, const float* embed, int K, int D, int* idx32, const int* flag_count, const int* flag_list,
+                 hipStream_t stream);
+int vq_loss_from_idx(const float* z, const float* embed, const int* idx32, int64_t N, int D, float commitment, double* partials,
+                     float* loss, hipStream_t stream);
+int vq_write_idx(const int* idx32, int64_t N, void* out, int idx_dtype, hipStream_t stream);
+}  // namespace vqae
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int PD = 8;                                    // projection_dim
+
+struct VqProjK {
+    const float* __restrict__ x;         // [N][C]
+    const float* __restrict__ wt_in;     // [C][8]   proj_in.weight transposed
+    const float* __restrict__ b_in;      // [8]
+    const float* __restrict__ embed;     // [K][8]
+    const float* __restrict__ w_out;     // [C][8]   proj_out.weight (PyTorch [C][8][1][1])
+    const float* __restrict__ b_out;     // [C]
+    float* __restrict__ out;             // [N][C]
+    float* __restrict__ z;               // [N][8]
+    int* __restrict__ idx32;             // [N]
+    float* __restrict__ margin;          // [N] or null
+    int* __restrict__ flag_count;
+    int* __restrict__ flag_list;
+    int64_t N;
+    int C, K;
+    float thr;
+};
+
+template <int DT> __device__ __forceinline__ float rnd16(float v) {
+    if (DT == VQAE_DT_BF16) return (float)(__bf16)v;
+    if (DT == VQAE_DT_F16) return (float)(_Float16)v;
+    return v;
+}
+
+constexpr int VP_THREADS = 128;
+
+template <int DT>
+__global__ __launch_bounds__(VP_THREADS)
+void vq_proj_fused_kernel(const VqProjK p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const s_win = lds;                                                // [C][8]
+    float* const s_wout = s_win + p.C * PD;                                  // [C][8]
+    float* const s_bout = s_wout + p.C * PD;                                 // [C]
+    float* const s_bin = s_bout + p.C;                                       // [8]
+    float* const s_emb = s_bin + PD;                                         // [Kpad4][8]
+    {
+        const int tid = threadIdx.x;
+        for (int i = tid; i < p.C * PD / 4; i += VP_THREADS) {
+            reinterpret_cast<f32x4*>(s_win)[i] = reinterpret_cast<const f32x4*>(p.wt_in)[i];
+            reinterpret_cast<f32x4*>(s_wout)[i] = reinterpret_cast<const f32x4*>(p.w_out)[i];
+        }
+        for (int i = tid; i < p.C / 4; i += VP_THREADS) reinterpret_cast<f32x4*>(s_bout)[i] = reinterpret_cast<const f32x4*>(p.b_out)[i];
+        if (tid < PD) s_bin[tid] = p.b_in[tid];
+        const int kpad = (p.K + 3) & ~3;
+        for (int i = tid; i < kpad * PD / 4; i += VP_THREADS)               // pad codes: copies of the last one (never win a strict '<')
+            reinterpret_cast<f32x4*>(s_emb)[i] = reinterpret_cast<const f32x4*>(p.embed)[i < p.K * PD / 4 ? i : (p.K - 1) * PD / 4 + (i & 1)];
+    }
+    __syncthreads();
+
+    const int64_t row_raw = (int64_t)blockIdx.x * VP_THREADS + threadIdx.x;
+    const bool live = row_raw < p.N;
+    const int64_t row = live ? row_raw : p.N - 1;                            // tail lanes recompute the last row, store nothing
+    const float* __restrict__ xr = p.x + row * p.C;
+
+    // ---- z = proj_in(x): k-ordered fp32 fma chain per output, bias last (the order of vqae_conv2d_f32's epilogue) ----
+    float z[PD];
+#pragma unroll
+    for (int j = 0; j < PD; ++j) z[j] = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < p.C; c += 4) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xe = rnd16<DT>(xv[e]);
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(s_win + (c + e) * PD);         // broadcast reads
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(s_win + (c + e) * PD + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { z[j] = __builtin_fmaf(xe, w0[j], z[j]); z[j + 4] = __builtin_fmaf(xe, w1[j], z[j + 4]); }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < PD; ++j) z[j] = rnd16<DT>(z[j] + s_bin[j]);
+    if (live) {
+        *reinterpret_cast<f32x4*>(p.z + row * PD) = (f32x4){z[0], z[1], z[2], z[3]};
+        *reinterpret_cast<f32x4*>(p.z + row * PD + 4) = (f32x4){z[4], z[5], z[6], z[7]};
+    }
+
+    // ---- tier-1 argmin over the codebook, 4 codes in flight to cover the fma latency -----------------------------------
+    float b1 = INFINITY, b2 = INFINITY;
+    int i1 = 0;
+    const int kpad = (p.K + 3) & ~3;
+#pragma unroll 2
+    for (int k0 = 0; k0 < kpad; k0 += 4) {
+        float s4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const f32x4 e0 = *reinterpret_cast<const f32x4*>(s_emb + (k0 + u) * PD);
+            const f32x4 e1 = *reinterpret_cast<const f32x4*>(s_emb + (k0 + u) * PD + 4);
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < PD; ++j) {
+                float d = z[j] - (j < 4 ? e0[j] : e1[j - 4]);
+                d = d * d;
+                a = __builtin_fmaf(d, d, a);
+            }
+            s4[u] = a;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                                        // k ascends: strict '<' keeps the lowest index
+            const bool better = s4[u] < b1;
+            if (k0 + u < p.K) b2 = fminf(b2, fmaxf(b1, s4[u]));              // a pad code (copy of K - 1) must not become "second best"
+            i1 = better ? k0 + u : i1;
+            b1 = fminf(b1, s4[u]);
+        }
+    }
+    if (live) {
+        p.idx32[row] = i1;
+        const float gap = b2 - b1;
+        if (p.margin) p.margin[row] = (b2 > 0.f) ? gap / b2 : 0.f;
+        if (!(gap > p.thr * b2)) {                                           // inside evaluation noise, exact tie, or NaN
+            const int slot = atomicAdd(p.flag_count, 1);
+            p.flag_list[slot] = (int)row;
+        }
+    }
+
+    // ---- q = z + (e[idx] - z); out = round(sum_j round(q_j) * W_out[c][j] + b_out[c]) ------------------------------------
+    float qr[PD];
+    {
+        const f32x4 e0 = *reinterpret_cast<const f32x4*>(s_emb + i1 * PD), e1 = *reinterpret_cast<const f32x4*>(s_emb + i1 * PD + 4);
+#pragma unroll
+        for (int j = 0; j < PD; ++j) {
+            const float ev = j < 4 ? e0[j] : e1[j - 4];
+            qr[j] = rnd16<DT>(z[j] + (ev - z[j]));
+        }
+    }
+    float* __restrict__ orow = p.out + row * p.C;
+#pragma unroll 2
+    for (int c = 0; c < p.C; c += 4) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(s_wout + (c + e) * PD);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(s_wout + (c + e) * PD + 4);
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a = __builtin_fmaf(qr[j], w0[j], a);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a = __builtin_fmaf(qr[j + 4], w1[j], a);
+            o[e] = rnd16<DT>(a + s_bout[c + e]);
+        }
+        if (live) *reinterpret_cast<f32x4*>(orow + c) = o;
+    }
+}
+
+// rows re-assigned by tier 2: recompute their output rows from the stored z and the corrected index
+template <int DT>
+__global__ __launch_bounds__(64)
+void vq_proj_patch_kernel(const VqProjK p) {
+    const int nflag = *p.flag_count;
+    for (int i = blockIdx.x * 64 + threadIdx.x; i < nflag; i += gridDim.x * 64) {
+        const int row = p.flag_list[i];
+        const float* __restrict__ zr = p.z + (int64_t)row * PD;
+        const float* __restrict__ eb = p.embed + p.idx32[row] * PD;
+        float q[PD];
+#pragma unroll
+        for (int j = 0; j < PD; ++j) q[j] = zr[j] + (eb[j] - zr[j]);
+        float qr[PD];
+#pragma unroll
+        for (int j = 0; j < PD; ++j) qr[j] = rnd16<DT>(q[j]);
+        float* __restrict__ orow = p.out + (int64_t)row * p.C;
+        for (int c = 0; c < p.C; ++c) {                                      // divergent lanes: plain vector loads
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < PD; ++j) a = __builtin_fmaf(qr[j], p.w_out[c * PD + j], a);
+            orow[c] = rnd16<DT>(a + p.b_out[c]);
+        }
+    }
+}
+
+template <int DT>
+int launch_vq_proj(const VqProjK& k, hipStream_t stream) {
+    const unsigned grid = (unsigned)vqae::ceil_div(k.N, VP_THREADS);
+    const size_t lds_bytes = ((size_t)k.C * (2 * PD + 1) + PD + (size_t)((k.K + 3) & ~3) * PD) * sizeof(float);
+    vqae::ProfScope prof(vqae::PROF_VQ_TIER1, stream, (double)k.N * (29.0 * k.K + 4.0 * PD * k.C));
+    vq_proj_fused_kernel<DT><<<grid, VP_THREADS, lds_bytes, stream>>>(k);
+    prof.done();
+    VQAE_LAUNCH_CHECK();
+    return VQAE_OK;
+}
+
+}  // namespace
+
+extern "C" size_t vqae_vq_projected_workspace_bytes(int64_t n_rows) {
+    return (size_t)(256 + 1024 * sizeof(double) + 2 * vqae::round_up(n_rows * 4, 256) + vqae::round_up(n_rows * PD * 4, 256) + 256);
+}
+
+extern "C" int vqae_vq_projected_f32(const float* x, const float* wt_in, const float* b_in, const float* embed, const float* w_out,
+                                     const float* b_out, int64_t N, int C, int D, int K, float commitment, int dtype,
+                                     void* idx_out, int idx_dtype, float* out, float* z_out, float* loss, float* margin,
+                                     void* ws, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VQAE_REQUIRE(N >= 0 && N < (1ll << 31), VQAE_ERR_INVALID, "vq_projected: n_rows %lld out of range", (long long)N);
+    VQAE_REQUIRE(D == PD, VQAE_ERR_UNSUPPORTED, "vq_projected: projection_dim %d (only %d is fused)", D, PD);
+    VQAE_REQUIRE(C >= 4 && C % 4 == 0 && C <= 512, VQAE_ERR_UNSUPPORTED, "vq_projected: channels %d", C);
+    VQAE_REQUIRE(K >= 1 && K <= 1024, VQAE_ERR_UNSUPPORTED, "vq_projected: n_codes %d (the codebook must fit LDS: <= 1024)", K);
+    VQAE_REQUIRE(dtype >= VQAE_DT_F32 && dtype <= VQAE_DT_F16, VQAE_ERR_INVALID, "vq_projected: dtype %d", dtype);
+    VQAE_REQUIRE(idx_dtype != VQAE_IDX_U8 || K <= 256, VQAE_ERR_INVALID, "vq_projected: u8 indices need K <= 256");
+    VQAE_REQUIRE(N == 0 || (x && wt_in && b_in && embed && w_out && b_out && idx_out && out && ws), VQAE_ERR_INVALID,
+                 "vq_projected: null pointer");
+    if (N == 0) {
+        if (loss) VQAE_HIP_CHECK(hipMemsetAsync(loss, 0, sizeof(float), stream));
+        return VQAE_OK;
+    }
+    char* w = (char*)ws;
+    VqProjK k;
+    k.flag_count = (int*)w; w += 256;
+    double* partials = (double*)w; w += 1024 * sizeof(double);
+    k.flag_list = (int*)w; w += vqae::round_up(N * 4, 256);
+    k.idx32 = (int*)w; w += vqae::round_up(N * 4, 256);
+    k.z = z_out ? z_out : (float*)w;
+    k.x = x; k.wt_in = wt_in; k.b_in = b_in; k.embed = embed; k.w_out = w_out; k.b_out = b_out; k.out = out;
+    k.margin = margin; k.N = N; k.C = C; k.K = K;
+    k.thr = (4.0f * (float)PD + 16.0f) * 5.9604645e-8f;           // as vqae_vq_forward_f32
+    VQAE_HIP_CHECK(hipMemsetAsync(k.flag_count, 0, 16, stream));
+    int rc = dtype == VQAE_DT_BF16 ? launch_vq_proj<VQAE_DT_BF16>(k, stream)
+           : dtype == VQAE_DT_F16 ? launch_vq_proj<VQAE_DT_F16>(k, stream) : launch_vq_proj<VQAE_DT_F32>(k, stream);
+    if (rc) return rc;
+    if ((rc = vqae::vq_tier2_run(k.z, embed, K, PD, k.idx32, k.flag_count, k.flag_list, stream))) return rc;
+    if (dtype == VQAE_DT_BF16) vq_proj_patch_kernel<VQAE_DT_BF16><<<4, 64, 0, stream>>>(k);
+    else if (dtype == VQAE_DT_F16) vq_proj_patch_kernel<VQAE_DT_F16><<<4, 64, 0, stream>>>(k);
+    else vq_proj_patch_kernel<VQAE_DT_F32><<<4, 64, 0, stream>>>(k);
+    VQAE_LAUNCH_CHECK();
+    if (loss && (rc = vqae::vq_loss_from_idx(k.z, embed, k.idx32, N, PD, commitment, partials, loss, stream))) return rc;
+    return vqae::vq_write_idx(k.idx32, N, idx_out, idx_dtype, stream);
+}

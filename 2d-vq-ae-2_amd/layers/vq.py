@@ -110,6 +110,15 @@ class ProjectedEMAVectorQuantizer2d(EMAVectorQuantizer):
 
     def forward(self, inputs):
         assert inputs.dim() == 4
+        if self.embedding_dim == 8 and not self.training:
+            # eval mode, the reference default projection_dim: one fused launch (csrc/vq_proj.hip)
+            with torch.no_grad():
+                x = ops.nchw_to_nhwc(inputs.detach().float())
+                B, H, W, C = x.shape
+                out, idx, loss, _, _ = ops.vq_projected(x.reshape(-1, C), self.proj_in.weight.detach(), self.proj_in.bias.detach(),
+                                                        self.embed, self.proj_out.weight.detach(), self.proj_out.bias.detach(),
+                                                        self.commitment_cost)
+                return ops.nhwc_to_nchw(out.reshape(B, H, W, C)), idx.reshape(B, H, W), loss
         w_in, w_out = self._weights()
         with torch.no_grad():
             x = ops.nchw_to_nhwc(inputs.detach().float())

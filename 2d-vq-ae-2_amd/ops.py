@@ -200,6 +200,34 @@ def vq_forward(z_flat, embed, commitment_cost=1.0, idx_dtype=torch.int64, want_q
     return q, idx, loss, margin
 
 
+def vq_projected(x_flat, proj_in_w, proj_in_b, embed, proj_out_w, proj_out_b, commitment_cost=1.0, idx_dtype=torch.int64,
+                 dtype=None, want_z=False, want_margin=False):
+    """ProjectedEMAVectorQuantizer2d.forward on x_flat [N, C] (NHWC rows) in one launch (projection_dim 8):
+    proj_in_w [8, C(,1,1)], proj_out_w [C, 8(,1,1)] as PyTorch stores them -> (out [N, C], idx [N], loss 0-d, z | None,
+    margin | None).  With `dtype` ('bf16' / 'f16') the two convolutions round like torch.autocast."""
+    _need_gpu(x_flat, proj_in_w, proj_in_b, embed, proj_out_w, proj_out_b)
+    x_flat = x_flat.contiguous().float()
+    N, C = x_flat.shape
+    K, D = embed.shape
+    dev = x_flat.device
+    code = L.dtype_code(dtype)
+    tdt = {L.DT_F32: None, L.DT_BF16: torch.bfloat16, L.DT_F16: torch.float16}[code]
+    r = (lambda t: t.to(tdt).float()) if tdt is not None else (lambda t: t)
+    wt_in = r(proj_in_w.reshape(D, C).float()).t().contiguous()
+    w_out = r(proj_out_w.reshape(C, D).float()).contiguous()
+    b_in, b_out = r(proj_in_b.float()).contiguous(), r(proj_out_b.float()).contiguous()
+    idx = torch.empty(N, dtype=idx_dtype, device=dev)
+    out = torch.empty_like(x_flat)
+    z = torch.empty((N, D), dtype=torch.float32, device=dev) if want_z else None
+    loss = torch.zeros((), dtype=torch.float32, device=dev)
+    margin = torch.empty(N, dtype=torch.float32, device=dev) if want_margin else None
+    ws = torch.empty(L.lib().vqae_vq_projected_workspace_bytes(N), dtype=torch.uint8, device=dev)
+    L.check(L.lib().vqae_vq_projected_f32(_p(x_flat), _p(wt_in), _p(b_in), _p(embed.contiguous().float()), _p(w_out), _p(b_out),
+                                          N, C, D, K, float(commitment_cost), code, _p(idx), idx_code(idx_dtype), _p(out),
+                                          _p(z), _p(loss), _p(margin), _p(ws), _stream()))
+    return out, idx, loss, z, margin
+
+
 def embed_code(idx, embed):
     _need_gpu(idx, embed)
     idx = idx.contiguous()

@@ -296,6 +296,15 @@ def main():
                                    "achieved": round(alg / (avg_ms * 1e-3) / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                                    "unit": "TFLOP/s", "traffic": None, "launches": k_n.value,
                                    "avg_ms": round(avg_ms, 4), "alg_flops_per_launch": alg}
+            elif spec.projection_dim == 8:
+                # fused projected quantiser (csrc/vq_proj.hip): one pass over the C-channel activation.  Algorithmic HBM
+                # bytes per row: C*4 read (x) + C*4 written (proj_out(q)) + 32 (z, kept for tier 2 / the loss) + 4 (index).
+                byts = M * (2.0 * C * 4 + 36.0)
+                res["roofline"] = {"kernel": "vq_proj_fused_kernel (proj_in + p=4 argmin + lookup + proj_out, projection_dim 8)",
+                                   "bound": "hbm", "achieved": round(byts / (avg_ms * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS,
+                                   "unit": "GB/s", "traffic": None, "launches": k_n.value, "avg_ms": round(avg_ms, 4),
+                                   "alg_bytes_per_launch": byts, "valu_ops_per_launch": alg,
+                                   "valu_frac_of_78.6Tops": round(alg / (avg_ms * 1e-3) / 78.6e12, 4)}
             else:                          # VQ tier 1: algorithmic HBM bytes = N*D*4 read + N*4 idx; VALU-bound
                 byts = M * spec.code_dim * 4.0 + M * 4.0
                 res["roofline"] = {"kernel": "vq_tier1_kernel", "bound": "hbm",

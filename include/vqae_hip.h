@@ -74,6 +74,25 @@ int vqae_vq_forward_f32(const float* z_dev, const float* embed_dev, int64_t n_ro
                         float commitment_cost, void* idx_dev, int idx_dtype, float* q_dev, float* loss_dev,
                         float* margin_dev, void* workspace_dev, void* stream);
 
+/* ProjectedEMAVectorQuantizer2d.forward (vq.py:190-192), projection_dim = 8 (the reference default,
+ * conf/model/layers/vq/projected_ema_vq_2d.yaml): proj_out(VQ(proj_in(x))) in one pass over the activation.
+ *   x_dev      [n_rows][channels] fp32 (NHWC activation)
+ *   wt_in_dev  [channels][8]   proj_in.weight  ([8][channels][1][1], vq.py:178-182) TRANSPOSED
+ *   b_in_dev   [8]             proj_in.bias
+ *   embed_dev  [n_codes][8]    buffer `embed` (vq.py:27)
+ *   w_out_dev  [channels][8]   proj_out.weight ([channels][8][1][1], vq.py:183-187) as stored
+ *   b_out_dev  [channels]      proj_out.bias
+ *   dtype      VQAE_DT_*: autocast rounding of the two convolutions (weights / biases pre-rounded by the caller)
+ *   idx_dev    [n_rows] idx_dtype; out_dev [n_rows][channels] = proj_out(z + (embed[idx] - z)); z_dev [n_rows][8] or NULL
+ *   loss_dev   commitment_cost * mean((z - embed[idx])^2) in the 8-D space, or NULL; margin_dev as vqae_vq_forward_f32
+ *   workspace_dev: vqae_vq_projected_workspace_bytes(n_rows) bytes.
+ * Errors: projection_dim != 8, channels % 4 != 0 -> VQAE_ERR_UNSUPPORTED. */
+size_t vqae_vq_projected_workspace_bytes(int64_t n_rows);
+int vqae_vq_projected_f32(const float* x_dev, const float* wt_in_dev, const float* b_in_dev, const float* embed_dev,
+                          const float* w_out_dev, const float* b_out_dev, int64_t n_rows, int channels, int projection_dim,
+                          int n_codes, float commitment_cost, int dtype, void* idx_dev, int idx_dtype, float* out_dev,
+                          float* z_dev, float* loss_dev, float* margin_dev, void* workspace_dev, void* stream);
+
 /* out[n][:] = embed[idx[n]][:]   (embed_code, vq.py:44-45 = F.embedding) */
 int vqae_embed_code_f32(const void* idx_dev, int idx_dtype, const float* embed_dev, int64_t n_rows, int n_codes,
                         int dim, float* out_dev, void* stream);

@@ -111,3 +111,104 @@ def test_ema_bookkeeping_matches_golden(amd, oracle):
         np.testing.assert_allclose(vq.cluster_size.cpu().numpy(), g[f"cluster_size{step}"], rtol=2e-6, atol=1e-6)
         assert abs(float(loss) - float(g[f"loss{step}"])) <= 2e-6 * float(g[f"loss{step}"])
     assert int(vq.first_pass) == 0
+
+
+# ---- fused projected quantiser (projection_dim = 8, the reference default): vqae_vq_projected_f32 --------------------
+def _proj_case(oracle, C, K, N, seed):
+    g = torch.Generator().manual_seed(seed)
+    p = {"vq.proj_in.weight": torch.randn(8, C, 1, 1, generator=g) / C ** 0.5, "vq.proj_in.bias": torch.randn(8, generator=g) * 0.1,
+         "vq.proj_out.weight": torch.randn(C, 8, 1, 1, generator=g) / 8 ** 0.5, "vq.proj_out.bias": torch.randn(C, generator=g) * 0.1,
+         "vq.embed": torch.randn(K, 8, generator=g)}
+    hw = int(N ** 0.5)
+    x = torch.randn(1, C, hw, N // hw, generator=g)
+    return p, x
+
+
+def test_vq_projected_index_exact_on_identical_z(amd, oracle):
+    """proj_in = a channel selection (z_j = x[c_j], exact in any summation order), so the fused kernel quantises
+    exactly the rows of the reference-recorded D = 8 fixture: indices must be bit-exact (incl. the duplicate-code /
+    near-tie rows that go through tier 2), q and the loss as the plain kernel's, out = proj_out(q)."""
+    g = load_golden("vq_D8_K256")
+    N, C = int(g["N"]), 128
+    z, embed = oracle.make_vq_case(8, 256, N, seed=int(g["seed"]))
+    sel = [3, 17, 29, 45, 64, 90, 101, 127]
+    w_in = torch.zeros(8, C)
+    for j, c in enumerate(sel):
+        w_in[j, c] = 1.0
+    gen = torch.Generator().manual_seed(1)
+    x = torch.zeros(N, C)
+    x[:, sel] = z
+    w_out, b_out = torch.randn(C, 8, generator=gen), torch.randn(C, generator=gen)
+    out, idx, loss, zz, margin = amd.ops.vq_projected(x.cuda(), w_in.cuda(), torch.zeros(8).cuda(), embed.cuda(), w_out.cuda(),
+                                                      b_out.cuda(), want_z=True, want_margin=True)
+    torch.cuda.synchronize()
+    assert torch.equal(zz.cpu(), z)
+    ref = g["idx"].astype(np.int64)
+    assert np.array_equal(idx.cpu().numpy(), ref), f"{(idx.cpu().numpy() != ref).sum()} index mismatches"
+    assert idx[:4].tolist() == [0, 1, 2, 3] and bool(torch.all(margin[:4].cpu() == 0))
+    assert abs(float(loss) - float(g["loss"])) <= 1e-6 * abs(float(g["loss"]))
+    q = z + (embed[idx.cpu()] - z)
+    want = torch.nn.functional.linear(q, w_out, b_out)
+    assert float((out.cpu() - want).abs().max()) <= 2e-6 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("N,C,K", [(4096, 128, 256), (1000, 128, 64), (1, 64, 32), (130, 256, 300)])
+def test_vq_projected_matches_oracle(amd, oracle, N, C, K):
+    """Random projections: against ProjectedEMAVectorQuantizer2d's oracle restatement (vq.py:190-192).  z differs from
+    oneDNN's by fp32 summation order, so indices must agree on every row whose margin exceeds that noise."""
+    hw = {4096: (64, 64), 1000: (25, 40), 1: (1, 1), 130: (10, 13)}[N]
+    g = torch.Generator().manual_seed(N + C)
+    p, _ = _proj_case(oracle, C, K, N, N + C)
+    x = torch.randn(1, C, *hw, generator=g)
+    want, oidx, oloss = oracle.projected_vq_forward(x, p, "vq.")
+    xf = x.permute(0, 2, 3, 1).reshape(N, C)
+    out, idx, loss, z, margin = amd.ops.vq_projected(xf.cuda(), p["vq.proj_in.weight"].cuda(), p["vq.proj_in.bias"].cuda(),
+                                                     p["vq.embed"].cuda(), p["vq.proj_out.weight"].cuda(), p["vq.proj_out.bias"].cuda(),
+                                                     want_z=True, want_margin=True)
+    torch.cuda.synchronize()
+    zo = torch.nn.functional.conv2d(x, p["vq.proj_in.weight"], p["vq.proj_in.bias"]).permute(0, 2, 3, 1).reshape(N, 8)
+    assert float((z.cpu() - zo).abs().max()) <= 2e-6 * max(1.0, float(zo.abs().max()))
+    same = idx.cpu() == oidx.reshape(-1)
+    clear = margin.cpu() > 1e-4
+    assert bool(same[clear].all()) and float(same.float().mean()) >= 0.999
+    wf = want.permute(0, 2, 3, 1).reshape(N, C)
+    assert float((out.cpu() - wf)[same].abs().max()) <= 1e-5 * float(wf.abs().max())
+    assert abs(float(loss) - float(oloss)) <= 1e-4 * float(oloss)
+
+
+@pytest.mark.parametrize("tag", ["bf16", "f16"])
+def test_vq_projected_autocast(amd, oracle, tag):
+    """Under torch.autocast the two projections are 16-bit convolutions (fp32 distance / q / loss): vs the oracle
+    under CPU autocast."""
+    N, C, K = 4096, 128, 256
+    p, x = _proj_case(oracle, C, K, N, 7)
+    dt = {"bf16": torch.bfloat16, "f16": torch.float16}[tag]
+    with torch.autocast("cpu", dtype=dt):
+        want, oidx, oloss = oracle.projected_vq_forward(x, p, "vq.")
+    xf = x.permute(0, 2, 3, 1).reshape(N, C)
+    out, idx, loss, _, _ = amd.ops.vq_projected(xf.cuda(), p["vq.proj_in.weight"].cuda(), p["vq.proj_in.bias"].cuda(),
+                                                p["vq.embed"].cuda(), p["vq.proj_out.weight"].cuda(), p["vq.proj_out.bias"].cuda(), dtype=tag)
+    torch.cuda.synchronize()
+    same = idx.cpu() == oidx.reshape(-1)
+    assert float(same.float().mean()) >= 0.995                    # a 16-bit rounding flip of z moves near-tie rows
+    wf = want.float().permute(0, 2, 3, 1).reshape(N, C)
+    ulp = 2.0 ** (-8 if tag == "bf16" else -11)
+    assert float((out.cpu() - wf)[same].abs().max()) <= 2 * ulp * float(wf.abs().max())
+
+
+def test_vq_projected_fused_equals_unfused_in_the_handle(amd, oracle, monkeypatch):
+    """cfg-A-style model (midA): handle with the fused quantiser vs VQAE_NO_VQ_FUSION=1 (proj_in conv -> VQ -> proj_out conv)."""
+    spec = oracle.SPECS["midA"]
+    p = oracle.make_params(spec, 0)
+    x = oracle.make_patches(4, 128, 3)
+    p = oracle.calibrate_codebook(x[:2], p, spec)
+    fused = amd.NativeVQAE(amd.SPECS["midA"], p)
+    monkeypatch.setenv("VQAE_NO_VQ_FUSION", "1")
+    plain = amd.NativeVQAE(amd.SPECS["midA"], p)
+    of, idf, lf = fused.forward(x.cuda())
+    op, idp, lp = plain.forward(x.cuda())
+    torch.cuda.synchronize()
+    assert float((idf == idp).float().mean()) >= 0.999
+    assert abs(float(lf) - float(lp)) <= 1e-5 * float(lp)
+    if bool((idf == idp).all()):
+        assert float((of - op).abs().max()) <= 1e-4 * float(op.abs().max())

@@ -102,6 +102,16 @@ __device__ __forceinline__ float elu_act(float v) {
 #endif
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter
+// (s_waitcnt vmcnt(0)): every global load in flight -- prefetched weight fragments, residual rows, the next tile's input
+// rows -- has to land before each phase boundary.  For kernels whose waves exchange data through LDS only (each lane
+// re-reads / overwrites only its own global elements; outputs are consumed by the next launch).
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
 

@@ -46,16 +46,7 @@ template <> struct E16<VQAE_DT_F16> {
     static __device__ __forceinline__ float rnd(float v) { return (float)(_Float16)v; }
 };
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter
-// (s_waitcnt vmcnt(0)): every global load in flight -- prefetched weight fragments, residual rows, the next tile's
-// input rows -- would have to land before each phase boundary.  These kernels exchange data between waves through
-// LDS only (each lane re-reads / overwrites its own global elements; t1' is consumed by the next launch), so the
-// barrier needs the LDS counter alone.
-__device__ __forceinline__ void lds_barrier() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
+using vqae::lds_barrier;                 // LDS-only workgroup barrier (common.h): global loads stay in flight across it
 
 struct T16K {
     const void* __restrict__ t1;     // [M][C] 16-bit: round16(ELU(round16(conv1) + b2a) + b2b), the conv2 operand
@@ -70,16 +61,19 @@ struct T16K {
 
 template <int C, int W, int MT> struct T16Cfg {
     static_assert(MT == 2 || MT == 4, "m-tiles per workgroup");
-    static_assert(W == 32 || W == 64 || W == 128, "grid width");
-    static_assert(C == 64 || C == 128 || C == 256, "channels");
+    static_assert(W == 32 || W == 64 || W == 128 || W == 256, "grid width");
+    static_assert(C == 32 || C == 64 || C == 128 || C == 256, "channels");
     static constexpr int NW = C / 32;                 // waves = 32-channel output slices
     static constexpr int NT = NW * 64;                // threads
-    static constexpr int SEG = W / 32;                // 32-pixel segments per image row
+    static constexpr int TW = W < 128 ? W : 128;      // columns a workgroup spans (wider grids: W / TW column blocks per row)
+    static constexpr int CB = W / TW;
+    static constexpr int SEG = TW / 32;               // 32-pixel segments per tile row
     static constexpr int R = MT / SEG;                // image rows per workgroup (MT m-tiles of 32 pixels)
-    static_assert(MT % SEG == 0, "whole image rows per workgroup");
+    static_assert(MT % SEG == 0, "whole tile rows per workgroup");
+    static constexpr int LW = TW + 2;                 // LDS row: the tile's columns + one (wrap-around) halo column each side
     static constexpr int PS = 2 * C + 16;             // LDS bytes per pixel: odd 16-B slot stride -> conflict-free b128 reads
     static constexpr int KS = C / 16;                 // k-slices per tap
-    static constexpr int LDS_BYTES = (R + 2) * W * PS;
+    static constexpr int LDS_BYTES = (R + 2) * LW * PS;
 };
 
 // Developer aid (off by default; tools/t16_trace.py): per-phase s_memtime stamps of every wave.
@@ -99,10 +93,10 @@ void trunk16_kernel(const T16K p) {
     using E = E16<DT>;
     using x8 = typename E::x8;
     using x4 = typename E::x4;
-    constexpr int NT = K::NT, SEG = K::SEG, R = K::R, PS = K::PS, KS = K::KS;
+    constexpr int NT = K::NT, SEG = K::SEG, R = K::R, PS = K::PS, KS = K::KS, TW = K::TW, LW = K::LW, CB = K::CB;
     constexpr int NS2 = 9 * KS;
     constexpr int NB = (3 * KS) % NB_MAX == 0 ? NB_MAX : 6;
-    extern __shared__ __attribute__((aligned(16))) char lds[];      // A: [(R + 2) * W pixels][PS];  T: [32 MT pixels][PS] over it
+    extern __shared__ __attribute__((aligned(16))) char lds[];      // A: [(R + 2) x (TW + 2) pixels][PS];  T: [32 MT pixels][PS] over it
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -116,10 +110,12 @@ void trunk16_kernel(const T16K p) {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int tiles_per_img = p.H / R;
+    const int tiles_per_img = (p.H / R) * CB;
     const int img = tile / tiles_per_img;
-    const int y0 = (tile - img * tiles_per_img) * R;
-    const int64_t pix0 = ((int64_t)img * p.H + y0) * W;             // first output pixel of this tile (NHWC pixel index)
+    const int t_in = tile - img * tiles_per_img;
+    const int y0 = (t_in / CB) * R, x0 = (t_in % CB) * TW;
+    const int64_t pix0 = ((int64_t)img * p.H + y0) * W + x0;        // first output pixel of this tile (NHWC pixel index)
+    auto moff = [](int mi) { return (mi / SEG) * W + (mi % SEG) * 32; };     // pixel offset of m-tile mi from pix0
     STAMP(0);
 
     // first ring of conv2 weight fragments (L2), requested ahead of the input rows
@@ -128,28 +124,36 @@ void trunk16_kernel(const T16K p) {
     x8 wq[NB];
 #pragma unroll
     for (int s = 0; s < NB; ++s) wq[s] = *reinterpret_cast<const x8*>(w2p + s * 1024);
-    // ---- stage the R + 2 input rows (wrap-around halo) in LDS, 16-bit, once --------------------------------------------
+    // ---- stage the (R + 2) x (TW + 2) input pixels (wrap-around halo rows and columns) in LDS, 16-bit, once --------------
     {
         constexpr int CPP = C * 2 / 16;                             // 16-byte chunks per pixel
-        constexpr int NCH = (R + 2) * W * CPP;
-        static_assert(NCH % NT == 0, "chunks per thread");
-        constexpr int PER = NCH / NT;
+        constexpr int NCH = (R + 2) * LW * CPP;
+        constexpr int PER = (NCH + NT - 1) / NT;
+        constexpr int GRP = 13;                                     // loads in flight per thread (bounds the staging registers)
         const char* const src = (const char*)p.t1 + (int64_t)img * p.H * W * C * 2;
-        u32x4 v[PER];
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int c = tid + i * NT;
-            const int px = c / CPP, part = c % CPP;
-            const int br = px / W, col = px % W;
-            int iy = y0 - 1 + br;
-            iy = iy < 0 ? iy + p.H : (iy >= p.H ? iy - p.H : iy);
-            v[i] = *reinterpret_cast<const u32x4*>(src + ((int64_t)(iy * W + col) * C * 2 + part * 16));
-        }
+        for (int i0 = 0; i0 < PER; i0 += GRP) {
+            u32x4 v[GRP];
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int c = tid + i * NT;
-            const int px = c / CPP, part = c % CPP;
-            *reinterpret_cast<u32x4*>(lds + px * PS + part * 16) = v[i];
+            for (int i = 0; i < GRP; ++i) {
+                if (i0 + i < PER) {
+                    int c = tid + (i0 + i) * NT;
+                    c = c < NCH ? c : NCH - 1;                      // ragged last sweep: re-read the last chunk
+                    const int px = c / CPP, part = c % CPP;
+                    const int br = px / LW, lx = px % LW;
+                    int iy = y0 - 1 + br;
+                    iy = iy < 0 ? iy + p.H : (iy >= p.H ? iy - p.H : iy);
+                    const int gx = (x0 + lx - 1) & (W - 1);
+                    v[i] = *reinterpret_cast<const u32x4*>(src + ((int64_t)(iy * W + gx) * C * 2 + part * 16));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < GRP; ++i) {
+                if (i0 + i < PER) {
+                    const int c = tid + (i0 + i) * NT;
+                    if (NCH % NT == 0 || c < NCH) *reinterpret_cast<u32x4*>(lds + (c / CPP) * PS + (c % CPP) * 16) = v[i];
+                }
+            }
         }
     }
 
@@ -157,7 +161,7 @@ void trunk16_kernel(const T16K p) {
 #pragma unroll
     for (int sg = 0; sg < SEG; ++sg)
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) abase[sg][dx] = ((sg * 32 + x + dx - 1) & (W - 1)) * PS + 16 * h;
+        for (int dx = 0; dx < 3; ++dx) abase[sg][dx] = (sg * 32 + x + dx) * PS + 16 * h;        // LDS column 0 is image column x0 - 1
     f32x16 acc[MT];
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
@@ -179,7 +183,7 @@ void trunk16_kernel(const T16K p) {
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) {
             const int row = mi / SEG, sg = mi % SEG;
-            dst[mi] = *reinterpret_cast<const x8*>(base + abase[sg][dx] + row * W * PS + ks * 32);
+            dst[mi] = *reinterpret_cast<const x8*>(base + abase[sg][dx] + row * LW * PS + ks * 32);
         }
     };
     x8 af[2][MT];
@@ -191,7 +195,7 @@ void trunk16_kernel(const T16K p) {
             const x8 wc = wq[s % NB];
             wq[s % NB] = *reinterpret_cast<const x8*>(wrow + (s + NB) * 1024);
             if (s + 1 < 3 * KS) load_a(af[(s + 1) & 1], arow, s + 1);
-            else if (dy < 2) load_a(af[0], arow + W * PS, 0);       // 3 * KS is even: the next tap row starts in af[0]
+            else if (dy < 2) load_a(af[0], arow + LW * PS, 0);       // 3 * KS is even: the next tap row starts in af[0]
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi) acc[mi] = E::mma(wc, af[s & 1][mi], acc[mi]);
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read
@@ -202,7 +206,7 @@ void trunk16_kernel(const T16K p) {
             }
         }
         wrow += 3 * KS * 1024;
-        arow += W * PS;
+        arow += LW * PS;
     }
     STAMP(2);
 
@@ -268,7 +272,7 @@ void trunk16_kernel(const T16K p) {
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) xr[mi][q] = *reinterpret_cast<const f32x4*>(xrow + (int64_t)mi * 32 * C + 8 * q);
+        for (int q = 0; q < 4; ++q) xr[mi][q] = *reinterpret_cast<const f32x4*>(xrow + (int64_t)moff(mi) * C + 8 * q);
 
     STAMP(3);
     gemm1x1(wp3);                                                   // conv3
@@ -290,7 +294,7 @@ void trunk16_kernel(const T16K p) {
                 t[e] = v;
                 u[e] = elu_act(v + p.n_b1a) + p.n_b1b;
             }
-            *reinterpret_cast<f32x4*>(xrow + (int64_t)mi * 32 * C + 8 * q) = t;
+            *reinterpret_cast<f32x4*>(xrow + (int64_t)moff(mi) * C + 8 * q) = t;
             if (NEXT) to_T(u, mi, q);
         }
     };
@@ -308,7 +312,7 @@ void trunk16_kernel(const T16K p) {
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = elu_act(E::rnd(acc[mi][4 * q + e]) + p.n_b2a) + p.n_b2b;
-                *reinterpret_cast<x4*>(trow + (int64_t)mi * 32 * C + 8 * q) = __builtin_convertvector(v, x4);
+                *reinterpret_cast<x4*>(trow + (int64_t)moff(mi) * C + 8 * q) = __builtin_convertvector(v, x4);
             }
     }
     STAMP(7);
@@ -367,6 +371,8 @@ int launch_t16_cw(const T16K& k, bool next, int c, int w, int64_t n_px, hipStrea
     if (c == 64 && w == 64) return launch_t16<64, 64, 4, DT>(k, next, n_px, stream);
     if (c == 128 && w == 64) return launch_t16<128, 64, 4, DT>(k, next, n_px, stream);
     if (c == 64 && w == 128) return launch_t16<64, 128, 4, DT>(k, next, n_px, stream);
+    if (c == 32 && w == 128) return launch_t16<32, 128, 4, DT>(k, next, n_px, stream);
+    if (c == 32 && w == 256) return launch_t16<32, 256, 4, DT>(k, next, n_px, stream);
     return vqae::fail(VQAE_ERR_UNSUPPORTED, "trunk16: C = %d on a %d-wide grid", c, w);
 }
 
@@ -379,8 +385,9 @@ bool trunk16_supported(int c, int h, int w, int dtype) {
     static const bool off = getenv("VQAE_NO_TRUNK16") && atoi(getenv("VQAE_NO_TRUNK16"));
     if (off || (dtype != VQAE_DT_BF16 && dtype != VQAE_DT_F16)) return false;
     const bool cw = (c == 128 && w == 32) || (c == 256 && w == 32) || (c == 64 && w == 64) || (c == 128 && w == 64) ||
-                    (c == 64 && w == 128);
-    return cw && h >= 1 && h % (128 / w) == 0;
+                    (c == 64 && w == 128) || (c == 32 && w == 128) || (c == 32 && w == 256);
+    const int tw = w < 128 ? w : 128;
+    return cw && h >= 1 && h % (128 / tw) == 0;
 }
 
 // + the ring's look-ahead past the last n-tile's fragments (trunk16_kernel reads, never uses, NB KiB beyond them)

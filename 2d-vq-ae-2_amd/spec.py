@@ -44,6 +44,7 @@ SPECS = {
     "mid16": VQAESpec(stem=16, n_down=2, n_pre=1, n_post=2, n_enc=2, num_embeddings=32, projection_dim=0),
     "midA": VQAESpec(stem=8, n_down=3, n_pre=1, n_post=2, n_enc=2, num_embeddings=64, projection_dim=8),
     "midC": VQAESpec(stem=64, n_down=2, n_pre=1, n_post=2, n_enc=2, num_embeddings=64, projection_dim=0),   # 64@128 -> 128@64 -> 256@32: cfg C's levels
+    "midW": VQAESpec(stem=32, n_down=2, n_pre=1, n_post=1, n_enc=1, num_embeddings=32, projection_dim=0),    # on 256x256: 32@256 (column-blocked tiles) -> 64@128 -> 128@64
     "tiny": VQAESpec(stem=8, n_down=2, n_pre=1, n_post=1, n_enc=2, num_embeddings=16, projection_dim=0),
     "tinyP": VQAESpec(stem=8, n_down=2, n_pre=1, n_post=1, n_enc=2, num_embeddings=32, projection_dim=8),
     # MBConv / EfficientNetV2 variant

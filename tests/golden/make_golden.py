@@ -352,10 +352,10 @@ if __name__ == "__main__":
         gen_model("BM", 2, 256, False)
     if "taps" in todo:
         print("G9 per-block taps (mid-size models reaching the production kernels)")
-        for nm in ("mid", "mid16", "midA", "midC"):
-            gen_model_taps(nm, 2, 128, None, "f32")
-            gen_model_taps(nm, 2, 128, torch.bfloat16, "bf16")
-            gen_model_taps(nm, 2, 128, torch.float16, "f16")
+        for nm, nb, sz in (("mid", 2, 128), ("mid16", 2, 128), ("midA", 2, 128), ("midC", 2, 128), ("midW", 1, 256)):
+            gen_model_taps(nm, nb, sz, None, "f32")
+            gen_model_taps(nm, nb, sz, torch.bfloat16, "bf16")
+            gen_model_taps(nm, nb, sz, torch.float16, "f16")
     if "driver" in todo:
         print("G5 driver"); gen_driver()
     if "ema" in todo:

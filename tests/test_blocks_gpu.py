@@ -95,7 +95,7 @@ def block_lists(oracle, spec):
 
 
 @pytest.mark.parametrize("tag", ["f32", "bf16", "f16"])
-@pytest.mark.parametrize("name", ["mid", "mid16", "midA", "midC"])
+@pytest.mark.parametrize("name", ["mid", "mid16", "midA", "midC", "midW"])
 def test_production_blocks_match_oracle_per_block(amd, oracle, name, tag):
     """Every block alone (count = 1): conv1 launch + fused tail without the next-block conv1, 'down' / 'up' blocks."""
     spec, p, x, taps = oracle_taps(oracle, name, tag)
@@ -124,7 +124,7 @@ def autocast_ctx(tag):
 
 
 @pytest.mark.parametrize("tag", ["f32", "bf16", "f16"])
-@pytest.mark.parametrize("name", ["mid", "mid16", "midA", "midC"])
+@pytest.mark.parametrize("name", ["mid", "mid16", "midA", "midC", "midW"])
 def test_fused_next_conv1_on_identical_inputs(amd, oracle, name, tag):
     """The cross-block fusion (conv2 + conv3 + the NEXT block's conv1 in one launch; t1 handed from launch to launch,
     as 16-bit in the 16-bit modes) on identical inputs: for every pair of consecutive blocks, y1 = blocks[i] alone and
@@ -153,7 +153,7 @@ def test_fused_next_conv1_on_identical_inputs(amd, oracle, name, tag):
 
 
 @pytest.mark.parametrize("tag", ["f32", "bf16", "f16"])
-@pytest.mark.parametrize("name", ["mid", "mid16", "midA", "midC"])
+@pytest.mark.parametrize("name", ["mid", "mid16", "midA", "midC", "midW"])
 def test_production_block_chains_match_oracle(amd, oracle, name, tag):
     """Every maximal chain of same-width 'same' blocks in one run (the production dispatch: chain-head conv1 + one
     fused launch per block) against the oracle's chain.  In fp32 the per-block bar scales with the chain length.  In
@@ -193,7 +193,7 @@ def test_production_block_chains_match_oracle(amd, oracle, name, tag):
 
 
 @pytest.mark.parametrize("tag", ["f32", "bf16", "f16"])
-@pytest.mark.parametrize("name", ["mid", "mid16", "midA", "midC"])
+@pytest.mark.parametrize("name", ["mid", "mid16", "midA", "midC", "midW"])
 def test_mid_models_end_to_end_vs_reference(amd, oracle, name, tag):
     """Whole forward of the mid-size models against the reference's recorded indices / output samples."""
     g = load_golden(f"taps_{name}_{tag}")

@@ -63,7 +63,7 @@ TDT = {"f32": None, "bf16": torch.bfloat16, "f16": torch.float16}
 
 
 @pytest.mark.parametrize("tag", ["f32", "bf16", "f16"])
-@pytest.mark.parametrize("name", ["mid", "mid16", "midA", "midC"])
+@pytest.mark.parametrize("name", ["mid", "mid16", "midA", "midC", "midW"])
 def test_block_taps_match_reference_fixture(oracle, name, tag):
     """Mid-size models (levels that reach the production kernels of cfg A/B/C): every block output of the oracle
     equals the reference's recorded one -- strided sample bit for bit, full tensor through its fp64 sum and sum of

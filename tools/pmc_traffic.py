@@ -25,17 +25,28 @@ def one_pass(counter, bench_args, tag):
     return rows
 
 
+def load_pass(counter, tag):
+    rows = []
+    for f in glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_{tag}_{counter}", "*", "*_counter_collection.csv")):
+        rows += [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--reuse", action="store_true", help="summarise the CSVs of an earlier run under gpurun_out/ (no GPU)")
     ap.add_argument("--config", default="B"); ap.add_argument("--dtype", default="f32"); ap.add_argument("--batch", type=int, default=256)
     a = ap.parse_args()
     bench_args = ["--config", a.config, "--dtype", a.dtype, "--batch", str(a.batch)]
-    pat = "wino_trunk_kernel" if a.dtype == "f32" and a.config != "C" else ("trunk16_kernel" if a.dtype != "f32" else "conv_mfma_kernel")
+    cch = 256 if a.config == "C" else 128                             # trunk channels: the dominant kernel's instantiation
+    kern = "wino_trunk_kernel" if a.dtype == "f32" and a.config != "C" else ("trunk16_kernel" if a.dtype != "f32" else "conv_mfma_kernel")
+    pat = f"{kern}<{cch}, "
     sources = {"wino_trunk_kernel": ["conv_wino.hip", "common.h"], "trunk16_kernel": ["trunk16.hip", "common.h"],
-               "conv_mfma_kernel": ["conv_mfma.hip", "common.h"]}[pat]
+               "conv_mfma_kernel": ["conv_mfma.hip", "common.h"]}[kern]
     tot = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        rows = [r for r in one_pass(counter, bench_args, f"{a.config}_{a.dtype}") if pat in r["Kernel_Name"]]
+        rows = [r for r in (load_pass(counter, f"{a.config}_{a.dtype}") if a.reuse else one_pass(counter, bench_args, f"{a.config}_{a.dtype}"))
+                if pat in r["Kernel_Name"]]
         big = max(int(r["Grid_Size"]) for r in rows)
         rows = [r for r in rows if int(r["Grid_Size"]) == big]          # full-batch launches only (not the calibration batch)
         tot[counter] = sum(float(r["Counter_Value"]) for r in rows) / len(rows) * 1024.0     # KiB -> bytes
@@ -44,7 +55,7 @@ def main():
     path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     d = json.load(open(path)) if os.path.exists(path) else {}
     d[f"{a.config}_{a.dtype}_B{a.batch}"] = {
-        "kernel": pat, "fetch_size_bytes_raw": tot["FETCH_SIZE"], "write_size_bytes": tot["WRITE_SIZE"],
+        "kernel": pat.rstrip(", ") + ", ...>", "fetch_size_bytes_raw": tot["FETCH_SIZE"], "write_size_bytes": tot["WRITE_SIZE"],
         "bytes_per_launch": 2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"], "launches_averaged": tot["launches"],
         "correction": "FETCH_SIZE x2 (gfx950 reports half of wide coalesced reads), KiB -> bytes; WRITE_SIZE as is",
         "sources": sources, "source_hash": kernel_source_hash(sources)}

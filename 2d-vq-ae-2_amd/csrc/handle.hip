@@ -254,7 +254,7 @@ int load_block(vqae_handle* h, const TensorMap& tm, const std::string& pre, int 
         VQAE_HIP_CHECK(hipDeviceSynchronize());
     }
     b->w1h = b->w2h = b->w3h = nullptr;
-    if (mode == MODE_SAME && cout == cin && h->cfg.compute_dtype != VQAE_DT_F32 && (cin == 32 || cin == 64 || cin == 128 || cin == 256)) {
+    if (mode == MODE_SAME && cout == cin && h->cfg.compute_dtype != VQAE_DT_F32 && (cin == 16 || cin == 32 || cin == 64 || cin == 128 || cin == 256)) {
         struct { float* src; int taps; void** dst; } m[3] = {{b->w1, 1, &b->w1h}, {b->w2, 9, &b->w2h}, {b->w3, 1, &b->w3h}};
         for (auto& e : m) {
             if ((rc = dev_alloc(h, vqae::trunk16_weight_bytes(cin, e.taps), e.dst))) return rc;

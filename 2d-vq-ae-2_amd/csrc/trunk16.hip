@@ -62,9 +62,12 @@ struct T16K {
 template <int C, int W, int MT> struct T16Cfg {
     static_assert(MT == 2 || MT == 4, "m-tiles per workgroup");
     static_assert(W == 32 || W == 64 || W == 128 || W == 256, "grid width");
-    static_assert(C == 32 || C == 64 || C == 128 || C == 256, "channels");
-    static constexpr int NW = C / 32;                 // waves = 32-channel output slices
-    static constexpr int NT = NW * 64;                // threads
+    static_assert(C == 16 || C == 32 || C == 64 || C == 128 || C == 256, "channels");
+    static constexpr int NW = C >= 32 ? C / 32 : 1;   // waves = 32-channel output slices (C = 16: one slice, half of it zero weights)
+    static constexpr int NQ = C >= 32 ? 4 : C / 8;    // channel quads of a lane that exist (register quad q <-> channels 8 q + 4 h ..)
+    static constexpr int WM = C <= 32 ? MT : 1;       // wave groups along the pixels: with one channel slice (C <= 32) every m-tile
+    static constexpr int MTW = MT / WM;               //   gets its own wave (4x the waves, each 4x shorter); MTW = m-tiles per wave
+    static constexpr int NT = NW * WM * 64;           // threads
     static constexpr int TW = W < 128 ? W : 128;      // columns a workgroup spans (wider grids: W / TW column blocks per row)
     static constexpr int CB = W / TW;
     static constexpr int SEG = TW / 32;               // 32-pixel segments per tile row
@@ -79,7 +82,7 @@ template <int C, int W, int MT> struct T16Cfg {
 // Developer aid (off by default; tools/t16_trace.py): per-phase s_memtime stamps of every wave.
 #ifdef VQAE_T16_TRACE
 __device__ unsigned long long* g_t16_trace = nullptr;
-#define STAMP(i) do { if (lane == 0 && g_t16_trace) g_t16_trace[((int64_t)blockIdx.x * 8 + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP(i) do { if (lane == 0 && g_t16_trace) g_t16_trace[((int64_t)blockIdx.x * 8 + wv) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMP(i) do {} while (0)
 #endif
@@ -87,20 +90,23 @@ __device__ unsigned long long* g_t16_trace = nullptr;
 constexpr int NB_MAX = 8;                             // weight-fragment ring depth (k-steps in flight per wave): 8, or 6 at C = 64
 
 template <int C, int W, int MT, int DT, bool NEXT>
-__global__ __launch_bounds__(C * 2, 2)
+__global__ __launch_bounds__((T16Cfg<C, W, MT>::NT), 2)
 void trunk16_kernel(const T16K p) {
     using K = T16Cfg<C, W, MT>;
     using E = E16<DT>;
     using x8 = typename E::x8;
     using x4 = typename E::x4;
-    constexpr int NT = K::NT, SEG = K::SEG, R = K::R, PS = K::PS, KS = K::KS, TW = K::TW, LW = K::LW, CB = K::CB;
+    constexpr int NT = K::NT, SEG = K::SEG, R = K::R, PS = K::PS, KS = K::KS, TW = K::TW, LW = K::LW, CB = K::CB, NQ = K::NQ;
+    constexpr int NW = K::NW, MTW = K::MTW;
     constexpr int NS2 = 9 * KS;
-    constexpr int NB = (3 * KS) % NB_MAX == 0 ? NB_MAX : 6;
+    constexpr int NB = (3 * KS) % NB_MAX == 0 ? NB_MAX : ((3 * KS) % 6 == 0 ? 6 : 3);
     extern __shared__ __attribute__((aligned(16))) char lds[];      // A: [(R + 2) x (TW + 2) pixels][PS];  T: [32 MT pixels][PS] over it
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // = n-tile: output channels [32 wave, 32 wave + 32)
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wv % NW;                                       // n-tile: output channels [32 wave, 32 wave + 32)
+    const int m0 = (wv / NW) * MTW;                                 // first of this wave's MTW m-tiles
     const int x = lane & 31, h = lane >> 5;
 
     // XCD-contiguous tile order: neighbouring row groups of an image (shared halo rows) meet in one L2 (speed only)
@@ -115,7 +121,7 @@ void trunk16_kernel(const T16K p) {
     const int t_in = tile - img * tiles_per_img;
     const int y0 = (t_in / CB) * R, x0 = (t_in % CB) * TW;
     const int64_t pix0 = ((int64_t)img * p.H + y0) * W + x0;        // first output pixel of this tile (NHWC pixel index)
-    auto moff = [](int mi) { return (mi / SEG) * W + (mi % SEG) * 32; };     // pixel offset of m-tile mi from pix0
+    auto moff = [&](int mi) { const int g = m0 + mi; return (g / SEG) * W + (g % SEG) * 32; };   // pixel offset of the wave's m-tile mi from pix0
     STAMP(0);
 
     // first ring of conv2 weight fragments (L2), requested ahead of the input rows
@@ -157,14 +163,17 @@ void trunk16_kernel(const T16K p) {
         }
     }
 
-    int abase[SEG][3];                                              // byte offset of (segment, dx)'s pixel column + lane's k half
+    int abase[MTW][3];                                              // byte offset of (own m-tile, dx): its tile row + pixel column + lane's k half
 #pragma unroll
-    for (int sg = 0; sg < SEG; ++sg)
+    for (int mi = 0; mi < MTW; ++mi)
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) abase[sg][dx] = (sg * 32 + x + dx) * PS + 16 * h;        // LDS column 0 is image column x0 - 1
-    f32x16 acc[MT];
+        for (int dx = 0; dx < 3; ++dx) {
+            const int g = m0 + mi;
+            abase[mi][dx] = ((g / SEG) * LW + (g % SEG) * 32 + x + dx) * PS + 16 * h;     // LDS column 0 is image column x0 - 1
+        }
+    f32x16 acc[MTW];
 #pragma unroll
-    for (int mi = 0; mi < MT; ++mi)
+    for (int mi = 0; mi < MTW; ++mi)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
     lds_barrier();
@@ -178,42 +187,50 @@ void trunk16_kernel(const T16K p) {
     // Software pipeline, pinned with sched_group_barrier (left alone, hipcc batches the ring's refills and waits for the
     // first of them right after issuing it: one exposed L2 round trip per 8 k-steps): per k-step ONE weight-fragment
     // load (for step s + NB), then 4 x { MFMA of step s, LDS fragment read of step s + 1 }.
-    auto load_a = [&](x8 (&dst)[MT], const char* base, int s) {
+    auto load_a = [&](x8 (&dst)[MTW], const char* base, int s) {
         const int dx = s / KS, ks = s % KS;
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
-            const int row = mi / SEG, sg = mi % SEG;
-            dst[mi] = *reinterpret_cast<const x8*>(base + abase[sg][dx] + row * LW * PS + ks * 32);
-        }
+        for (int mi = 0; mi < MTW; ++mi) dst[mi] = *reinterpret_cast<const x8*>(base + abase[mi][dx] + ks * 32);
     };
-    x8 af[2][MT];
+    x8 af[2][MTW];
     load_a(af[0], arow, 0);
+    if constexpr ((3 * KS) % 2 == 0) {
 #pragma unroll 1
-    for (int dy = 0; dy < 3; ++dy) {
+        for (int dy = 0; dy < 3; ++dy) {
 #pragma unroll
-        for (int s = 0; s < 3 * KS; ++s) {
-            const x8 wc = wq[s % NB];
-            wq[s % NB] = *reinterpret_cast<const x8*>(wrow + (s + NB) * 1024);
-            if (s + 1 < 3 * KS) load_a(af[(s + 1) & 1], arow, s + 1);
-            else if (dy < 2) load_a(af[0], arow + LW * PS, 0);       // 3 * KS is even: the next tap row starts in af[0]
+            for (int s = 0; s < 3 * KS; ++s) {
+                const x8 wc = wq[s % NB];
+                wq[s % NB] = *reinterpret_cast<const x8*>(wrow + (s + NB) * 1024);
+                if (s + 1 < 3 * KS) load_a(af[(s + 1) & 1], arow, s + 1);
+                else if (dy < 2) load_a(af[0], arow + LW * PS, 0);   // 3 * KS is even: the next tap row starts in af[0]
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi) acc[mi] = E::mma(wc, af[s & 1][mi], acc[mi]);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read
+                for (int mi = 0; mi < MTW; ++mi) acc[mi] = E::mma(wc, af[s & 1][mi], acc[mi]);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+                for (int mi = 0; mi < MTW; ++mi) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+                }
             }
+            wrow += 3 * KS * 1024;
+            arow += LW * PS;
         }
-        wrow += 3 * KS * 1024;
-        arow += LW * PS;
+    } else {                                                        // C = 16: 9 k-steps in all, fully unrolled (static buffer parity)
+#pragma unroll
+        for (int g = 0; g < 9 * KS; ++g) {
+            const x8 wc = wq[g % NB];
+            wq[g % NB] = *reinterpret_cast<const x8*>(wrow + (g + NB) * 1024);
+            if (g + 1 < 9 * KS) load_a(af[(g + 1) & 1], arow + ((g + 1) / (3 * KS)) * LW * PS, (g + 1) % (3 * KS));
+#pragma unroll
+            for (int mi = 0; mi < MTW; ++mi) acc[mi] = E::mma(wc, af[g & 1][mi], acc[mi]);
+        }
     }
     STAMP(2);
 
     // result layout: lane = pixel x of m-tile mi, register r = channel 32 wave + (r & 3) + 8 (r >> 2) + 4 h
     const int cbase = wave * 32 + 4 * h;                            // + 8 q + {0..3}
     auto to_T = [&](const f32x4& v, int mi, int q) {                // 4 consecutive channels of one pixel -> T, 16-bit
-        *reinterpret_cast<x4*>(lds + (mi * 32 + x) * PS + (cbase + 8 * q) * 2) = __builtin_convertvector(v, x4);
+        *reinterpret_cast<x4*>(lds + ((m0 + mi) * 32 + x) * PS + (cbase + 8 * q) * 2) = __builtin_convertvector(v, x4);
     };
     // 1x1 tails: acc = Wf (C x C, row operand, fragments through the ring w1) x T (K = C).  The ring is filled by
     // w_prefetch well ahead of its gemm (before the barrier / activation work in front of it).
@@ -227,15 +244,15 @@ void trunk16_kernel(const T16K p) {
     };
     auto gemm1x1 = [&](const char* wp) {
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
+        for (int mi = 0; mi < MTW; ++mi)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
         lds_barrier();                                            // T complete
-        auto load_b = [&](x8 (&dst)[MT], int s) {
+        auto load_b = [&](x8 (&dst)[MTW], int s) {
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi) dst[mi] = *reinterpret_cast<const x8*>(lds + (mi * 32 + x) * PS + 16 * h + s * 32);
+            for (int mi = 0; mi < MTW; ++mi) dst[mi] = *reinterpret_cast<const x8*>(lds + ((m0 + mi) * 32 + x) * PS + 16 * h + s * 32);
         };
-        x8 bf[2][MT];
+        x8 bf[2][MTW];
         load_b(bf[0], 0);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -243,10 +260,10 @@ void trunk16_kernel(const T16K p) {
             if (s + NR < KS) w1[s % NR] = *reinterpret_cast<const x8*>(wp + (s + NR) * 1024);
             if (s + 1 < KS) load_b(bf[(s + 1) & 1], s + 1);
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi) acc[mi] = E::mma(wc, bf[s & 1][mi], acc[mi]);
+            for (int mi = 0; mi < MTW; ++mi) acc[mi] = E::mma(wc, bf[s & 1][mi], acc[mi]);
             if (s + NR < KS) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi) {
+            for (int mi = 0; mi < MTW; ++mi) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 if (s + 1 < KS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
@@ -257,9 +274,9 @@ void trunk16_kernel(const T16K p) {
     const char* const wp3 = w_prefetch(p.w3f);                      // in flight across the barrier and the activation work
     lds_barrier();                                                // every wave is done reading A
 #pragma unroll
-    for (int mi = 0; mi < MT; ++mi)
+    for (int mi = 0; mi < MTW; ++mi)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = elu_act(E::rnd(acc[mi][4 * q + e]) + p.act_a) + p.act_b;
@@ -268,11 +285,11 @@ void trunk16_kernel(const T16K p) {
 
     // residual rows: requested now, consumed after conv3 (16 B per lane: 4 consecutive channels of one pixel)
     float* const xrow = p.xio + (pix0 + x) * C + cbase;
-    f32x4 xr[MT][4];
+    f32x4 xr[MTW][4];
 #pragma unroll
-    for (int mi = 0; mi < MT; ++mi)
+    for (int mi = 0; mi < MTW; ++mi)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) xr[mi][q] = *reinterpret_cast<const f32x4*>(xrow + (int64_t)moff(mi) * C + 8 * q);
+        for (int q = 0; q < NQ; ++q) xr[mi][q] = *reinterpret_cast<const f32x4*>(xrow + (int64_t)moff(mi) * C + 8 * q);
 
     STAMP(3);
     gemm1x1(wp3);                                                   // conv3
@@ -284,7 +301,7 @@ void trunk16_kernel(const T16K p) {
     if (NEXT) lds_barrier();                                      // conv3 finished reading T
     auto finish = [&](int mi, const f32x4 (&xv)[4]) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             f32x4 t, u;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -299,16 +316,16 @@ void trunk16_kernel(const T16K p) {
         }
     };
 #pragma unroll
-    for (int mi = 0; mi < MT; ++mi) finish(mi, xr[mi]);
+    for (int mi = 0; mi < MTW; ++mi) finish(mi, xr[mi]);
     STAMP(5);
     if constexpr (NEXT) {
         gemm1x1(wp1);                                               // the next block's conv1
         STAMP(6);
         typename E::elem* const trow = (typename E::elem*)p.t1n + (pix0 + x) * C + cbase;
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
+        for (int mi = 0; mi < MTW; ++mi)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < NQ; ++q) {
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = elu_act(E::rnd(acc[mi][4 * q + e]) + p.n_b2a) + p.n_b2b;
@@ -326,13 +343,13 @@ template <typename EL>
 __global__ void pack16_kernel(const float* __restrict__ w, int c, int taps, EL* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int ks_n = c / 16;
-    if (i >= (int64_t)c * taps * c) return;
+    if (i >= (int64_t)(c < 32 ? 32 : c) * taps * c) return;
     const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
     const int64_t st = i >> 9;
     const int s = (int)(st % (taps * ks_n)), nt = (int)(st / (taps * ks_n));
     const int tap = s / ks_n, ks = s % ks_n;
     const int n = nt * 32 + (lane & 31), k = ks * 16 + 8 * (lane >> 5) + j;
-    out[i] = (EL)w[(int64_t)n * taps * c + tap * c + k];
+    out[i] = (EL)w[(int64_t)n * taps * c + tap * c + k];              // rows >= c (c = 16) are the packed layout's zero padding
 }
 
 template <typename EL>
@@ -373,6 +390,8 @@ int launch_t16_cw(const T16K& k, bool next, int c, int w, int64_t n_px, hipStrea
     if (c == 64 && w == 128) return launch_t16<64, 128, 4, DT>(k, next, n_px, stream);
     if (c == 32 && w == 128) return launch_t16<32, 128, 4, DT>(k, next, n_px, stream);
     if (c == 32 && w == 256) return launch_t16<32, 256, 4, DT>(k, next, n_px, stream);
+    if (c == 16 && w == 128) return launch_t16<16, 128, 4, DT>(k, next, n_px, stream);
+    if (c == 16 && w == 256) return launch_t16<16, 256, 4, DT>(k, next, n_px, stream);
     return vqae::fail(VQAE_ERR_UNSUPPORTED, "trunk16: C = %d on a %d-wide grid", c, w);
 }
 
@@ -385,18 +404,18 @@ bool trunk16_supported(int c, int h, int w, int dtype) {
     static const bool off = getenv("VQAE_NO_TRUNK16") && atoi(getenv("VQAE_NO_TRUNK16"));
     if (off || (dtype != VQAE_DT_BF16 && dtype != VQAE_DT_F16)) return false;
     const bool cw = (c == 128 && w == 32) || (c == 256 && w == 32) || (c == 64 && w == 64) || (c == 128 && w == 64) ||
-                    (c == 64 && w == 128) || (c == 32 && w == 128) || (c == 32 && w == 256);
+                    (c == 64 && w == 128) || (c == 32 && w == 128) || (c == 32 && w == 256) || (c == 16 && w == 128) || (c == 16 && w == 256);
     const int tw = w < 128 ? w : 128;
     return cw && h >= 1 && h % (128 / tw) == 0;
 }
 
 // + the ring's look-ahead past the last n-tile's fragments (trunk16_kernel reads, never uses, NB KiB beyond them)
-size_t trunk16_weight_bytes(int c, int taps) { return (size_t)c * c * taps * 2 + (size_t)(NB_MAX + 1) * 1024; }
+size_t trunk16_weight_bytes(int c, int taps) { return (size_t)(c < 32 ? 32 : c) * c * taps * 2 + (size_t)(NB_MAX + 1) * 1024; }
 
 // packed (vqae_conv_pack_weight_f32, rounded) fp32 weights [c][taps * c] on the device -> 16-bit fragment order
 int trunk16_pack_weight(const float* w_packed_dev, int c, int taps, int dtype, void* out_dev, hipStream_t stream) {
-    VQAE_REQUIRE(c % 32 == 0 && (taps == 1 || taps == 9), VQAE_ERR_INVALID, "trunk16_pack_weight: c %d taps %d", c, taps);
-    const int64_t n = (int64_t)c * c * taps;
+    VQAE_REQUIRE(c % 16 == 0 && (taps == 1 || taps == 9), VQAE_ERR_INVALID, "trunk16_pack_weight: c %d taps %d", c, taps);
+    const int64_t n = (int64_t)(c < 32 ? 32 : c) * c * taps;
     if (dtype == VQAE_DT_BF16) pack16_kernel<__bf16><<<(unsigned)ceil_div(n, 256), 256, 0, stream>>>(w_packed_dev, c, taps, (__bf16*)out_dev);
     else pack16_kernel<_Float16><<<(unsigned)ceil_div(n, 256), 256, 0, stream>>>(w_packed_dev, c, taps, (_Float16*)out_dev);
     VQAE_LAUNCH_CHECK();

@@ -7,6 +7,7 @@ module nesting and parameter names match, so reference state_dicts load unchange
 configs compose is implemented: one VQ level, Fixup blocks, no shortcut blocks; anything else raises
 NotImplementedError.
 """
+import weakref
 from typing import Sequence
 
 import torch
@@ -80,14 +81,34 @@ class _NativeMixin:
             return torch.get_autocast_gpu_dtype()
         return None
 
+    def _weights_signature(self):
+        """Changes whenever a parameter / buffer is modified in place (optimizer step, `.data.copy_`, the VQ's EMA
+        update) or replaced: the device snapshot is then rebuilt on the next call instead of silently going stale."""
+        return tuple((id(t), t._version) for t in list(self.parameters()) + list(self.buffers()))
+
     def native(self) -> NativeVQAE:
+        owner = getattr(self, "_owner", None)
+        if owner is not None and owner() is not None:
+            return owner().native()
         dt = self._autocast_dtype()
-        if self._native is None:
-            self._native = {}
+        sig = self._weights_signature()
+        if self._native is None or self._native.get("sig") != sig:
+            for k, v in (self._native or {}).items():
+                if k != "sig":
+                    v.close()
+            self._native = {"sig": sig}
         if dt not in self._native:
             sd = {self._prefix + k: v for k, v in self.state_dict().items()}
             self._native[dt] = NativeVQAE(self._spec(), sd, compute_dtype=dt)
         return self._native[dt]
+
+    @staticmethod
+    def _inference_only(*tensors):
+        """These mirrors are inference-only (no autograd through the HIP path; SURVEY.md section 2 scopes training out):
+        fail loudly instead of returning values that would train to nothing."""
+        if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+            raise NotImplementedError("vqae_amd.model mirrors run the HIP inference path: inputs that require grad are not "
+                                      "supported (wrap the call in torch.no_grad())")
 
     def refresh(self):
         """Drop the device snapshot of the weights (call after changing parameters)."""
@@ -138,6 +159,7 @@ class Encoder(_NativeMixin, nn.Module):
 
     def forward(self, x: torch.Tensor):
         """-> ((q,), (idx,), (loss,)), low-res first (model.py:189-217)."""
+        self._inference_only(x)
         q, idx, loss = self.native().encode(x.float(), "NCHW")
         return (q,), (idx,), (loss,)
 
@@ -169,6 +191,7 @@ class Decoder(_NativeMixin, nn.Module):
         """x: encodings low-res -> high-res (one level) -> reconstruction (model.py:274-291)."""
         if len(x) != 1:
             raise NotImplementedError("only single-level decoders are implemented")
+        self._inference_only(x[0])
         return self.native().decode(x[0].float(), "NCHW")
 
 
@@ -181,20 +204,18 @@ class VQAE(_NativeMixin, nn.Module):
         self.optim_conf, self.loss_f_conf = optim_conf, loss_f_conf
         self.encoder = Encoder(**_strip(encoder_conf))
         self.decoder = Decoder(**_strip(decoder_conf))
+        # the children run on the parent's handle (one device copy of the weights; it encodes and decodes)
+        object.__setattr__(self.encoder, "_owner", weakref.ref(self))
+        object.__setattr__(self.decoder, "_owner", weakref.ref(self))
         for k, v in kwargs.items():
             setattr(self, k, v)
 
     def _spec(self):
         return self.encoder._spec()
 
-    def native(self):
-        n = super().native()
-        self.encoder._native = self._native          # share the device copies of the weights
-        if self.decoder is not None:
-            self.decoder._native = self._native
-        return n
 
     def forward(self, data: torch.Tensor):
+        self._inference_only(data)
         out, _, loss = self.native().forward(data.float(), "NCHW", want_idx=False)
         return out, (loss,)
 

@@ -100,3 +100,16 @@ def test_lightning_checkpoint_import(amd, oracle, tmp_path):
     got = m.state_dict()
     for k, v in p.items():
         assert torch.equal(got[k], v), k
+
+
+def test_mirrors_are_inference_only():
+    """Inputs that require grad raise instead of returning values without a graph (no GPU needed: raised before any launch)."""
+    import torch
+    import vqae_amd
+    from vqae_amd.model import VQAE
+    m = VQAE.from_spec(vqae_amd.SPECS["tiny"])
+    x = torch.zeros(1, 3, 32, 32, requires_grad=True)
+    with pytest.raises(NotImplementedError):
+        m(x)
+    with pytest.raises(NotImplementedError):
+        m.encoder(x)

@@ -270,3 +270,28 @@ def test_handle_error_paths(amd, oracle):
     q, idx, _ = e.encode(torch.zeros(1, 3, 32, 32).cuda())
     with pytest.raises(AssertionError):
         e.decode(q)
+
+
+def test_module_mirror_tracks_inplace_weight_changes(amd, oracle):
+    """The mirrors snapshot their weights into a device handle; an in-place change (optimizer step, `.data.copy_`, the
+    VQ's EMA update of `embed`) must be picked up on the next call, not silently ignored."""
+    from vqae_amd.model import VQAE
+    g = load_golden("model_tiny")
+    spec, p = golden_params(oracle, "tiny", g)
+    model = VQAE.from_spec(amd.SPECS["tiny"])
+    model.load_state_dict(p, strict=False)
+    model = model.cuda().eval()
+    x = torch.from_numpy(g["x"]).cuda()
+    (q0,), (i0,), _ = model.encoder(x)
+    out0, _ = model(x)
+    with torch.no_grad():
+        model.encoder.in_stem.weight.mul_(1.5)                       # in place: only `_version` changes
+    (q1,), (i1,), _ = model.encoder(x)
+    assert not torch.equal(i0, i1)
+    p2 = dict(p)
+    p2["encoder.in_stem.weight"] = p["encoder.in_stem.weight"] * 1.5
+    nat = amd.NativeVQAE(amd.SPECS["tiny"], p2)
+    assert torch.equal(nat.encode(x)[1], i1)
+    with torch.no_grad():
+        model.encoder.in_stem.weight.div_(1.5)
+    assert model.encoder.native() is model.native()                  # children run on the parent's handle

@@ -137,6 +137,7 @@ struct vqae_handle {
     void* vq_ws = nullptr;
     size_t vq_ws_bytes = 0;
     float* loss_scratch = nullptr;
+    int device = 0;                        // the HIP device the weights / workspaces live on (one handle per process and device)
     bool has_encoder = false, has_decoder = false;
     bool fuse_trunk = true;                // conv2 + conv3 (+ next conv1) in one launch at the 128-channel trunk
     bool t1_ready = false;                 // buf[1] already holds the current block's t1
@@ -637,8 +638,18 @@ int ensure_workspace(vqae_handle* h, int B, int in_h, int in_w) {
     return VQAE_OK;
 }
 
+// A handle's weights and workspaces live on the device that was current in vqae_create; kernels are launched on the
+// caller's current device.  One process per GPU is the deployment model: refuse anything else.
+int check_device(const vqae_handle* h) {
+    int dev = -1;
+    VQAE_HIP_CHECK(hipGetDevice(&dev));
+    VQAE_REQUIRE(dev == h->device, VQAE_ERR_INVALID, "handle was created on HIP device %d but the current device is %d", h->device, dev);
+    return VQAE_OK;
+}
+
 int check_geometry(const vqae_handle* h, int B, int in_h, int in_w) {
     const int f = 1 << h->cfg.n_down;
+    if (int rc = check_device(h)) return rc;
     VQAE_REQUIRE(B >= 0, VQAE_ERR_INVALID, "negative batch");
     VQAE_REQUIRE(in_h >= f && in_w >= f && in_h % f == 0 && in_w % f == 0, VQAE_ERR_INVALID,
                  "input %dx%d must be a positive multiple of 2^n_down = %d", in_h, in_w, f);
@@ -730,6 +741,7 @@ extern "C" int vqae_create(const vqae_config* cfg, const vqae_tensor* tensors, i
 
     vqae_handle* h = new vqae_handle();
     h->cfg = *cfg;
+    if (hipGetDevice(&h->device) != hipSuccess) { delete h; return vqae::fail(VQAE_ERR_HIP, "hipGetDevice failed"); }
     h->fuse_trunk = !(getenv("VQAE_NO_TRUNK_FUSION") && atoi(getenv("VQAE_NO_TRUNK_FUSION")));
     h->up_conv_first = !(getenv("VQAE_NO_UP_REORDER") && atoi(getenv("VQAE_NO_UP_REORDER")));
     h->use_wino = !(getenv("VQAE_NO_WINOGRAD") && atoi(getenv("VQAE_NO_WINOGRAD")));
@@ -911,6 +923,7 @@ extern "C" int vqae_decode(vqae_handle* h, const float* q, int B, int qh, int qw
     VQAE_REQUIRE(h && q && out, VQAE_ERR_INVALID, "vqae_decode: null pointer");
     VQAE_REQUIRE(h->has_decoder, VQAE_ERR_INVALID, "vqae_decode: handle was created without decoder.* tensors");
     VQAE_REQUIRE(B >= 0 && qh >= 1 && qw >= 1, VQAE_ERR_INVALID, "vqae_decode: bad shape");
+    if (int rcd = check_device(h)) return rcd;
     if (B == 0) return VQAE_OK;
     int rc;
     if ((rc = ensure_workspace(h, B, qh << h->cfg.n_down, qw << h->cfg.n_down))) return rc;
@@ -929,6 +942,7 @@ extern "C" int vqae_decode_indices(vqae_handle* h, const void* idx, int idx_dtyp
     VQAE_REQUIRE(h && idx && out, VQAE_ERR_INVALID, "vqae_decode_indices: null pointer");
     VQAE_REQUIRE(h->has_decoder && h->embed, VQAE_ERR_INVALID, "vqae_decode_indices: handle needs decoder.* tensors and a codebook");
     VQAE_REQUIRE(B >= 0 && qh >= 1 && qw >= 1, VQAE_ERR_INVALID, "vqae_decode_indices: bad shape");
+    if (int rcd = check_device(h)) return rcd;
     if (B == 0) return VQAE_OK;
     int rc;
     if ((rc = ensure_workspace(h, B, qh << h->cfg.n_down, qw << h->cfg.n_down))) return rc;
@@ -958,6 +972,7 @@ extern "C" int vqae_run_blocks(vqae_handle* h, int side, int first, int count, c
     VQAE_REQUIRE(first >= 0 && count >= 1 && (size_t)first + (size_t)count <= v.size(), VQAE_ERR_INVALID,
                  "vqae_run_blocks: blocks [%d, %d) of %zu", first, first + count, v.size());
     VQAE_REQUIRE(B >= 0 && in_h >= 1 && in_w >= 1, VQAE_ERR_INVALID, "vqae_run_blocks: bad shape");
+    if (int rcd = check_device(h)) return rcd;
     int H = in_h, W = in_w;
     if (B == 0) return VQAE_OK;
     // workspace: the widest tensor any block of the range touches (an 'up' block's upsampled 2C tensor is 4x its input)

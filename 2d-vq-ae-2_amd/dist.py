@@ -61,6 +61,13 @@ def all_gather_shares(mine: torch.Tensor, async_op: bool = False):
     if ws == 1:
         out[0].copy_(mine)
         return out, None
+    if mine.is_cuda and dist.get_backend() == "gloo":
+        # gloo moves host memory: rehearsals of the sharded GPU path on a box without RCCL peers (several ranks on one GPU,
+        # tests/test_driver_gpu.py) stage the (small) share through the host; under "nccl" (RCCL) the tensors stay in HBM
+        host = torch.empty((ws,) + tuple(mine.shape), dtype=mine.dtype)
+        dist.all_gather_into_tensor(host.view(-1), mine.contiguous().view(-1).cpu())
+        out.copy_(host)
+        return out, None
     work = dist.all_gather_into_tensor(out.view(-1), mine.contiguous().view(-1), async_op=async_op)
     return out, work
 

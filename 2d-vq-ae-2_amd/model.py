@@ -77,8 +77,8 @@ class _NativeMixin:
     def _autocast_dtype():
         """The reference's extraction runs `with torch.autocast('cuda')` (extract_embeddings.py:124-125);
         inside such a context the mirrors use the matching 16-bit autocast handle."""
-        if torch.is_autocast_enabled():
-            return torch.get_autocast_gpu_dtype()
+        if torch.is_autocast_enabled("cuda"):
+            return torch.get_autocast_dtype("cuda")
         return None
 
     def _weights_signature(self):

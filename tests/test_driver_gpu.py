@@ -123,3 +123,47 @@ def test_run_eval_default_is_the_reference_fp16_autocast(amd, oracle):
         assert np.array_equal(idx32.cpu().numpy(), g32["idx"].astype(np.int64))
         assert agree16 >= 0.99, agree16
     assert nat.compute_dtype == 0 and nat.with_dtype(torch.float16).compute_dtype == 2
+
+
+def _sharded_gpu_worker(rank, ws, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        import vqae_amd
+        from oracle import vqae_oracle as O
+        from vqae_amd.extract_embeddings import SyntheticSlideDataset, get_encodings
+        torch.cuda.set_device(0)
+        g = load_golden("model_tiny")
+        p = O.make_params(O.SPECS["tiny"], 0)
+        p["encoder.vq_layers.0.embed"] = torch.from_numpy(g["embed"])
+        nat = vqae_amd.NativeVQAE(vqae_amd.SPECS["tiny"], p)
+        ds = SyntheticSlideDataset([(3, 2), (2, 3)], patch_size=32, raw=True, names=["a", "b"])
+        sharded = dict(get_encodings(nat, ds, batch_size=5, num_workers=0))                 # ranks split every batch 3 + 2
+        alone = dict(get_encodings(nat, ds, batch_size=5, num_workers=0, shard=False))      # this rank encodes everything
+        ok = set(sharded) == set(alone) and all(np.array_equal(sharded[k], alone[k]) and sharded[k].dtype == alone[k].dtype for k in alone)
+        q.put((rank, ok, ""))
+    except Exception:
+        import traceback
+        q.put((rank, False, traceback.format_exc()))
+    dist.destroy_process_group()
+
+
+def test_sharded_get_encodings_two_ranks_on_one_gpu(amd):
+    """The sharded run_eval / get_encodings path with the real HIP encoder: two processes (one GPU here, so both use
+    cuda:0 and the share gather travels over gloo through the host -- dist.all_gather_shares) must each assemble exactly
+    the grids a single process produces.  On a multi-GPU node the same code runs one rank per GPU over RCCL."""
+    import os
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + os.getpid() % 90
+    procs = [ctx.Process(target=_sharded_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert all(r[1] for r in res), [r[2] for r in res if not r[1]]

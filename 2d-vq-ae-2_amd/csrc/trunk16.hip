@@ -76,7 +76,13 @@ template <int C, int W, int MT> struct T16Cfg {
     static constexpr int LW = TW + 2;                 // LDS row: the tile's columns + one (wrap-around) halo column each side
     static constexpr int PS = 2 * C + 16;             // LDS bytes per pixel: odd 16-B slot stride -> conflict-free b128 reads
     static constexpr int KS = C / 16;                 // k-slices per tap
-    static constexpr int LDS_BYTES = (R + 2) * LW * PS;
+    static constexpr int IMG_BYTES = (R + 2) * LW * PS;
+    // C >= 256: the epilogues' global accesses go through a wave-private LDS transpose (32 pixels x this wave's 32 channels)
+    // so that every wave-wide access is 1 KiB of whole 128-byte lines instead of 64 row pieces of 16 bytes
+    static constexpr bool EPI = C >= 256;             // measured: C = 256 -2.5 %, C = 128 / 64 neutral (kept direct)
+    static constexpr int EPI_RS = 144;                // scratch row stride (128 B of fp32 + one 16-B slot: conflict-free both ways)
+    static constexpr int EPI_BYTES = EPI ? 32 * EPI_RS : 0;
+    static constexpr int LDS_BYTES = IMG_BYTES + NW * WM * EPI_BYTES;
 };
 
 // Developer aid (off by default; tools/t16_trace.py): per-phase s_memtime stamps of every wave.
@@ -283,13 +289,23 @@ void trunk16_kernel(const T16K p) {
             to_T(v, mi, q);                                         // the cast is the conv3 input rounding
         }
 
-    // residual rows: requested now, consumed after conv3 (16 B per lane: 4 consecutive channels of one pixel)
-    float* const xrow = p.xio + (pix0 + x) * C + cbase;
+    // residual rows: requested now, consumed after conv3.
+    //   direct form (C < 64): 16 B per lane = 4 consecutive channels of the lane's pixel (a 512-byte-strided row piece);
+    //   EPI form: whole lines -- instruction i of an m-tile covers pixels 8 i .. 8 i + 7 x this wave's 128 bytes (lane L:
+    //   pixel 8 i + L / 8, 16-byte chunk L % 8) -- and a wave-private LDS transpose turns them into the MFMA layout.
+    constexpr bool EPI = K::EPI;
+    constexpr int RS = K::EPI_RS;
+    char* const S = lds + K::IMG_BYTES + wv * K::EPI_BYTES;         // this wave's transpose scratch (EPI)
+    float* const xrow = p.xio + (pix0 + x) * C + cbase;             // direct form
+    char* const xlin = (char*)(p.xio + pix0 * C) + ((lane >> 3) * C + wave * 32) * 4 + (lane & 7) * 16;   // EPI form, + 8 i pixels
     f32x4 xr[MTW][4];
 #pragma unroll
     for (int mi = 0; mi < MTW; ++mi)
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) xr[mi][q] = *reinterpret_cast<const f32x4*>(xrow + (int64_t)moff(mi) * C + 8 * q);
+        for (int q = 0; q < NQ; ++q) {
+            if constexpr (EPI) xr[mi][q] = *reinterpret_cast<const f32x4*>(xlin + ((int64_t)moff(mi) + 8 * q) * (C * 4));
+            else xr[mi][q] = *reinterpret_cast<const f32x4*>(xrow + (int64_t)moff(mi) * C + 8 * q);
+        }
 
     STAMP(3);
     gemm1x1(wp3);                                                   // conv3
@@ -299,7 +315,15 @@ void trunk16_kernel(const T16K p) {
 
     // ---- out = round(conv3) * scale + bias4 + x, in place; u = round(ELU(out + b1a') + b1b') for the next conv1 --------
     if (NEXT) lds_barrier();                                      // conv3 finished reading T
-    auto finish = [&](int mi, const f32x4 (&xv)[4]) {
+    char* const s_lin = S + (lane >> 3) * RS + (lane & 7) * 16;     // scratch address of this lane's line piece (+ 8 i rows)
+    char* const s_mma = S + x * RS + h * 16;                        // ... of its MFMA-layout piece (+ 32 q bytes)
+    auto finish = [&](int mi, f32x4 (&xv)[4]) {
+        if constexpr (EPI) {                                        // line pieces -> scratch -> MFMA layout (LDS runs a wave's accesses in order)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(s_lin + 8 * q * RS) = xv[q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xv[q] = *reinterpret_cast<const f32x4*>(s_mma + 32 * q);
+        }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             f32x4 t, u;
@@ -311,8 +335,14 @@ void trunk16_kernel(const T16K p) {
                 t[e] = v;
                 u[e] = elu_act(v + p.n_b1a) + p.n_b1b;
             }
-            *reinterpret_cast<f32x4*>(xrow + (int64_t)moff(mi) * C + 8 * q) = t;
+            if constexpr (EPI) *reinterpret_cast<f32x4*>(s_mma + 32 * q) = t;
+            else *reinterpret_cast<f32x4*>(xrow + (int64_t)moff(mi) * C + 8 * q) = t;
             if (NEXT) to_T(u, mi, q);
+        }
+        if constexpr (EPI) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<f32x4*>(xlin + ((int64_t)moff(mi) + 8 * q) * (C * 4)) = *reinterpret_cast<const f32x4*>(s_lin + 8 * q * RS);
         }
     };
 #pragma unroll
@@ -322,15 +352,26 @@ void trunk16_kernel(const T16K p) {
         gemm1x1(wp1);                                               // the next block's conv1
         STAMP(6);
         typename E::elem* const trow = (typename E::elem*)p.t1n + (pix0 + x) * C + cbase;
+        // EPI form: 16-bit rows of this wave are 64 bytes: instruction i covers pixels 16 i .. 16 i + 15 (lane L: pixel 16 i + L / 4, chunk L % 4)
+        char* const tlin = (char*)((typename E::elem*)p.t1n + pix0 * C) + ((lane >> 2) * C + wave * 32) * 2 + (lane & 3) * 16;
+        char* const s_tl = S + (lane >> 2) * 80 + (lane & 3) * 16;  // 80-byte scratch rows for the 16-bit tile
+        char* const s_tm = S + x * 80 + h * 8;
 #pragma unroll
-        for (int mi = 0; mi < MTW; ++mi)
+        for (int mi = 0; mi < MTW; ++mi) {
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = elu_act(E::rnd(acc[mi][4 * q + e]) + p.n_b2a) + p.n_b2b;
-                *reinterpret_cast<x4*>(trow + (int64_t)moff(mi) * C + 8 * q) = __builtin_convertvector(v, x4);
+                if constexpr (EPI) *reinterpret_cast<x4*>(s_tm + 16 * q) = __builtin_convertvector(v, x4);
+                else *reinterpret_cast<x4*>(trow + (int64_t)moff(mi) * C + 8 * q) = __builtin_convertvector(v, x4);
             }
+            if constexpr (EPI) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    *reinterpret_cast<u32x4*>(tlin + ((int64_t)moff(mi) + 16 * i) * (C * 2)) = *reinterpret_cast<const u32x4*>(s_tl + 16 * i * 80);
+            }
+        }
     }
     STAMP(7);
 }

@@ -1,4 +1,4 @@
-// Winograd F(2x2, 3x3) form of the trunk Fixup blocks, fp32: C = 128 channels on a 32-wide grid (the code-grid
+// Winograd F(2x2, 3x3) form of the trunk Fixup blocks, fp32: C = 128 (and 256) channels on a 32-wide grid (the code-grid
 // resolution), C = 64 on a 64-wide grid and C = 32 on a 128-wide grid (the levels above it):
 //   conv2 (3x3 circular, conv_block.py:208)  as  Y = A^T [ sum_c (G g G^T) .* (B^T d B) ] A
 // followed, in the same workgroup, by the block's conv3 (+ scale / bias4 / residual) and the NEXT block's conv1 --
@@ -11,7 +11,7 @@
 // weights on the host), a few VALU instructions per element.  Result differs from the direct form by fp32 rounding
 // only (measured in tests/test_model_gpu.py::test_winograd_trunk_equals_direct).
 //
-// Work split (written for C = 128; C = 64 and C = 32 in brackets).  A 256-thread workgroup owns 4 image rows =
+// Work split (written for C = 128; C = 64 and C = 32 in brackets; C = 256: same tile, 512 threads = 8 channel slices).  A 256-thread workgroup owns 4 image rows =
 // 128 [256, 512] output pixels = 32 [64, 128] Winograd tiles (2 tile rows x 16 [32, 64] tile columns).  A wave owns 32
 // output channels and 32 tiles: 4 channel slices x 1 tile group [2 x 2, 1 x 4].  The 4x4 transformed domain is walked
 // one row xi at a time (4 passes):
@@ -54,7 +54,7 @@ struct WinoK {
 // Developer aid (off by default): per-phase s_memtime stamps of every wave -> gpurun_out/wino_trace.bin.  It showed that
 // the cost of this kernel's first version sat in the L1 tag pipe (row-major weight fragments), not in HBM or the MFMAs.
 #ifdef VQAE_WINO_TRACE
-#define STAMP(i) do { if (lane == 0 && p.trace) p.trace[((int64_t)blockIdx.x * 4 + wave) * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP(i) do { if (lane == 0 && p.trace && wave < 4) p.trace[((int64_t)blockIdx.x * 4 + wave) * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMP(i) do {} while (0)
 #endif
@@ -62,18 +62,20 @@ struct WinoK {
 constexpr int BPF = 6;                   // weight-fragment prefetch distance (k-slices)
 
 template <int C> struct WinoCfg {
-    static constexpr int W = C == 128 ? 32 : (C == 64 ? 64 : 128);   // columns a workgroup spans (the image may be k times wider)
+    static constexpr int W = C >= 128 ? 32 : (C == 64 ? 64 : 128);   // columns a workgroup spans (the image may be k times wider)
+    static constexpr int NT = C == 256 ? 512 : 256;    // threads: at C = 256 eight waves (one per 32-channel slice), one workgroup per CU
+    static constexpr int NW = NT / 64;
     static constexpr int PX = 4 * W;                   // output pixels per workgroup (4 image rows)
     static constexpr int TILES = PX / 4;               // 2x2 output tiles per workgroup
     static constexpr int TC = W / 2;                   // tile columns
     static constexpr int NS = C / 32;                  // 32-channel slices
     static constexpr int KS = C / 8;                   // k-slices (8 channels) per GEMM
     static constexpr int C4 = C / 4;                   // float4 per pixel
-    static constexpr int RP = 256 / C4;                // pixels (or tile columns) covered by one sweep of the 256 threads
+    static constexpr int RP = NT / C4;                 // pixels (or tile columns) covered by one sweep of the workgroup's threads
     static constexpr int LDT = C + 4;                  // LDS row stride (floats): conflict-free ds_read_b128 fragments
     static constexpr int NI = C >= 64 ? 2 : 1;         // tails: 32-channel tiles per wave
-    static constexpr int WN = C / (32 * NI);           //        waves along the channels, 4 / WN along the pixels
-    static constexpr int MI = PX / ((4 / WN) * 32);    //        32-pixel tiles per wave (MI * NI = 4 accumulators)
+    static constexpr int WN = C / (32 * NI);           //        waves along the channels, NW / WN along the pixels
+    static constexpr int MI = PX / ((NW / WN) * 32);   //        32-pixel tiles per wave (MI * NI = 4 accumulators)
     static constexpr int LDS_BYTES = PX * LDT * 4;     // V[4][TILES][LDT] and T[PX][LDT] overlay each other
 };
 
@@ -89,7 +91,7 @@ __device__ __forceinline__ int frag_offset(int n, int k, int c, int sk = 8) {   
 // Winograd form differs from the direct one by fp32 rounding only).
 // WIDE: the grid is k > 1 workgroup spans wide (column blocks); the exact-width case keeps all geometry compile-time.
 template <int C, int TAIL, int DT, bool WIDE>
-__global__ __launch_bounds__(256, 2)
+__global__ __launch_bounds__((WinoCfg<C>::NT), 2)
 void wino_trunk_kernel(const WinoK p) {
     using K = WinoCfg<C>;
     auto rnd = [](float v) -> float {
@@ -415,7 +417,7 @@ void wino_trunk_kernel(const WinoK p) {
 // row-coalesced 128-bit stores.  An HBM-bound launch (2 C floats per pixel); the implicit-GEMM engine ran it at
 // 2.3 TB/s because its per-workgroup setup is paid on four K steps.
 template <int C>
-__global__ __launch_bounds__(256, 2)
+__global__ __launch_bounds__((WinoCfg<C>::NT), 2)
 void fixup_conv1_kernel(const float* __restrict__ x, const float* __restrict__ w1f, float pa, float pb, float aa, float ab,
                         float* __restrict__ y) {
     using K = WinoCfg<C>;
@@ -538,9 +540,9 @@ int launch_wino_w(const WinoK& k, bool chain, hipStream_t stream) {
     const unsigned grid = (unsigned)(k.M / K::PX);
     // executed matrix work: 16 GEMMs of K = C per 4 output pixels (K_eff = 4 C per pixel) + the 1x1 tails
     const double flops = 2.0 * (double)k.M * C * (4.0 * C + C + (chain ? C : 0));
-    vqae::ProfScope prof(C == 128 ? vqae::PROF_CONV3X3_TRUNK : vqae::PROF_NONE, stream, flops);
-    if (chain) wino_trunk_kernel<C, 2, DT, WIDE><<<grid, 256, K::LDS_BYTES, stream>>>(k);
-    else wino_trunk_kernel<C, 1, DT, WIDE><<<grid, 256, K::LDS_BYTES, stream>>>(k);
+    vqae::ProfScope prof(C >= 128 ? vqae::PROF_CONV3X3_TRUNK : vqae::PROF_NONE, stream, flops);
+    if (chain) wino_trunk_kernel<C, 2, DT, WIDE><<<grid, K::NT, K::LDS_BYTES, stream>>>(k);
+    else wino_trunk_kernel<C, 1, DT, WIDE><<<grid, K::NT, K::LDS_BYTES, stream>>>(k);
     prof.done();
     VQAE_LAUNCH_CHECK();
     return VQAE_OK;
@@ -555,10 +557,10 @@ int launch_wino(const WinoK& k, bool chain, hipStream_t stream) {
 
 namespace vqae {
 
-// fp32: C in {128, 64, 32} on a grid whose width is a multiple of the workgroup's column span (32, 64, 128); 16-bit autocast
+// fp32: C in {256, 128, 64, 32} on a grid whose width is a multiple of the workgroup's column span (32, 64, 128); 16-bit autocast
 // modes: C = 32 only (the wider levels have a 16-bit MFMA kernel with fused tails, conv_mfma.hip)
 bool wino_trunk_supported(int c, int h, int w, int dtype) {
-    const int span = c == 128 ? 32 : (c == 64 ? 64 : (c == 32 ? 128 : 0));
+    const int span = (c == 256 || c == 128) ? 32 : (c == 64 ? 64 : (c == 32 ? 128 : 0));
     if (span == 0 || (dtype != VQAE_DT_F32 && c != 32)) return false;
     return w >= span && w % span == 0 && h >= 4 && h % 4 == 0;
 }
@@ -574,8 +576,8 @@ int wino_transform_weight(const float* w_oihw_dev, int c, int dtype, float* U_de
 
 // chain-head conv1 (fixup_conv1_kernel): fp32, C in {128, 64, 32}, M a multiple of the kernel's pixel tile
 bool fixup_conv1_supported(int c, int64_t m) {
-    if (c != 128 && c != 64 && c != 32) return false;
-    const int px = c == 128 ? 128 : (c == 64 ? 256 : 512);
+    if (c != 256 && c != 128 && c != 64 && c != 32) return false;
+    const int px = c >= 128 ? 128 : (c == 64 ? 256 : 512);
     return m > 0 && m % px == 0;
 }
 
@@ -588,8 +590,8 @@ static int launch_conv1(const float* x, const float* w1f, float pa, float pb, fl
         VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)fixup_conv1_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES));
         attr_set = true;
     }
-    ProfScope prof(C == 128 ? PROF_CONV1X1_TRUNK : PROF_NONE, stream, 2.0 * (double)m * C * C);
-    fixup_conv1_kernel<C><<<(unsigned)(m / K::PX), 256, K::LDS_BYTES, stream>>>(x, w1f, pa, pb, aa, ab, y);
+    ProfScope prof(C >= 128 ? PROF_CONV1X1_TRUNK : PROF_NONE, stream, 2.0 * (double)m * C * C);
+    fixup_conv1_kernel<C><<<(unsigned)(m / K::PX), K::NT, K::LDS_BYTES, stream>>>(x, w1f, pa, pb, aa, ab, y);
     prof.done();
     VQAE_LAUNCH_CHECK();
     return VQAE_OK;
@@ -600,6 +602,7 @@ int fixup_conv1(const float* x, const float* w1f, float pa, float pb, float aa, 
     VQAE_REQUIRE(x && w1f && y, VQAE_ERR_INVALID, "fixup_conv1: null pointer");
     VQAE_REQUIRE(fixup_conv1_supported(c, m), VQAE_ERR_UNSUPPORTED, "fixup_conv1: C = %d, M = %lld", c, (long long)m);
     VQAE_REQUIRE(m / 128 < (1ll << 31), VQAE_ERR_UNSUPPORTED, "fixup_conv1: too many pixels");
+    if (c == 256) return launch_conv1<256>(x, w1f, pa, pb, aa, ab, y, m, stream);
     if (c == 128) return launch_conv1<128>(x, w1f, pa, pb, aa, ab, y, m, stream);
     if (c == 64) return launch_conv1<64>(x, w1f, pa, pb, aa, ab, y, m, stream);
     return launch_conv1<32>(x, w1f, pa, pb, aa, ab, y, m, stream);
@@ -635,6 +638,7 @@ int wino_trunk_tail(const float* t1, const float* U, const float* w3, float act_
 #endif
     const int rc = dtype == VQAE_DT_BF16 ? launch_wino<32, VQAE_DT_BF16>(k, w1n != nullptr, stream)
                  : dtype == VQAE_DT_F16 ? launch_wino<32, VQAE_DT_F16>(k, w1n != nullptr, stream)
+                 : c == 256 ? launch_wino<256>(k, w1n != nullptr, stream)
                  : c == 128 ? launch_wino<128>(k, w1n != nullptr, stream)
                  : (c == 64 ? launch_wino<64>(k, w1n != nullptr, stream) : launch_wino<32>(k, w1n != nullptr, stream));
 #ifdef VQAE_WINO_TRACE

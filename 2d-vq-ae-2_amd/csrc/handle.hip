@@ -242,7 +242,7 @@ int load_block(vqae_handle* h, const TensorMap& tm, const std::string& pre, int 
     if ((rc = upload_packed(h, p, b->br, b->br, k2, &b->w2))) return rc;
     b->wU = b->w1f = b->w3f = nullptr;
     const bool wino = mode == MODE_SAME && cout == cin && h->use_wino &&       // conv_wino.hip: fp32 C = 32/64/128; 16-bit C = 32
-                      (h->cfg.compute_dtype == VQAE_DT_F32 ? (cin == 128 || cin == 64 || cin == 32) : cin == 32);
+                      (h->cfg.compute_dtype == VQAE_DT_F32 ? (cin == 256 || cin == 128 || cin == 64 || cin == 32) : cin == 32);
     if (wino && (rc = upload_wino(h, p, cin, &b->wU))) return rc;
     if ((rc = find(tm, pre + ".branch_conv3.weight", (int64_t)cout * b->br, &p))) return rc;
     if ((rc = upload_packed(h, p, cout, b->br, 1, &b->w3))) return rc;

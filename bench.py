@@ -266,7 +266,7 @@ def main():
                 #                  outputs) -- `achieved`/`frac` price the executed MFMA work, i.e. real pipe utilisation;
                 #                  `direct_equivalent_*` price the same launch as a direct conv (may exceed 1.0 of peak).
                 direct = 2.0 * M * C * (9 * C + C + C)
-                wino = C in (128, 64, 32) and not os.environ.get("VQAE_NO_WINOGRAD")
+                wino = C in (256, 128, 64, 32) and not os.environ.get("VQAE_NO_WINOGRAD")
                 traffic, tnote = pmc_traffic(f"{args.config}_{args.dtype}_B{B}")
                 res["roofline"] = {"kernel": "wino_trunk_kernel: trunk Fixup block, conv2 3x3 as Winograd F(2x2,3x3) + fused conv3 / "
                                              "next-conv1 tails" if wino else "conv_mfma_kernel TAIL: trunk Fixup block, direct conv2 + fused tails",

@@ -88,9 +88,12 @@ template <int C, int W, int MT> struct T16Cfg {
 // Developer aid (off by default; tools/t16_trace.py): per-phase s_memtime stamps of every wave.
 #ifdef VQAE_T16_TRACE
 __device__ unsigned long long* g_t16_trace = nullptr;
+__device__ int g_t16_dbg = 0;         // experiments: 1 skip the staging loads, 2 skip the residual loads, 4 skip the stores
+#define DBG(bit) (g_t16_dbg & (bit))
 #define STAMP(i) do { if (lane == 0 && g_t16_trace) g_t16_trace[((int64_t)blockIdx.x * 8 + wv) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMP(i) do {} while (0)
+#define DBG(bit) false
 #endif
 
 constexpr int NB_MAX = 8;                             // weight-fragment ring depth (k-steps in flight per wave): 8, or 6 at C = 64
@@ -115,6 +118,13 @@ void trunk16_kernel(const T16K p) {
     const int m0 = (wv / NW) * MTW;                                 // first of this wave's MTW m-tiles
     const int x = lane & 31, h = lane >> 5;
 
+#ifdef VQAE_T16_TRACE
+    if (!NEXT && lane == 0 && g_t16_trace) {                        // slot 6 (unused without NEXT): where this workgroup ran
+        const unsigned hw = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);           // HW_ID[15:0] (cu_id, sh_id, se_id in 15:8)
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);          // XCC_ID[3:0]
+        g_t16_trace[((int64_t)blockIdx.x * 8 + wv) * 8 + 6] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
     // XCD-contiguous tile order: neighbouring row groups of an image (shared halo rows) meet in one L2 (speed only)
     int tile;
     {
@@ -156,7 +166,8 @@ void trunk16_kernel(const T16K p) {
                     int iy = y0 - 1 + br;
                     iy = iy < 0 ? iy + p.H : (iy >= p.H ? iy - p.H : iy);
                     const int gx = (x0 + lx - 1) & (W - 1);
-                    v[i] = *reinterpret_cast<const u32x4*>(src + ((int64_t)(iy * W + gx) * C * 2 + part * 16));
+                    if (!DBG(1)) v[i] = *reinterpret_cast<const u32x4*>(src + ((int64_t)(iy * W + gx) * C * 2 + part * 16));
+                    else v[i] = u32x4{0x3c003c00u + (unsigned)c, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
                 }
             }
 #pragma unroll
@@ -304,7 +315,8 @@ void trunk16_kernel(const T16K p) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             if constexpr (EPI) xr[mi][q] = *reinterpret_cast<const f32x4*>(xlin + ((int64_t)moff(mi) + 8 * q) * (C * 4));
-            else xr[mi][q] = *reinterpret_cast<const f32x4*>(xrow + (int64_t)moff(mi) * C + 8 * q);
+            else if (!DBG(2)) xr[mi][q] = *reinterpret_cast<const f32x4*>(xrow + (int64_t)moff(mi) * C + 8 * q);
+            else xr[mi][q] = f32x4{1.f, 2.f, 3.f, (float)lane};
         }
 
     STAMP(3);
@@ -336,7 +348,7 @@ void trunk16_kernel(const T16K p) {
                 u[e] = elu_act(v + p.n_b1a) + p.n_b1b;
             }
             if constexpr (EPI) *reinterpret_cast<f32x4*>(s_mma + 32 * q) = t;
-            else *reinterpret_cast<f32x4*>(xrow + (int64_t)moff(mi) * C + 8 * q) = t;
+            else if (!DBG(4) || t[0] == 12345.f) *reinterpret_cast<f32x4*>(xrow + (int64_t)moff(mi) * C + 8 * q) = t;
             if (NEXT) to_T(u, mi, q);
         }
         if constexpr (EPI) {
@@ -364,7 +376,7 @@ void trunk16_kernel(const T16K p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = elu_act(E::rnd(acc[mi][4 * q + e]) + p.n_b2a) + p.n_b2b;
                 if constexpr (EPI) *reinterpret_cast<x4*>(s_tm + 16 * q) = __builtin_convertvector(v, x4);
-                else *reinterpret_cast<x4*>(trow + (int64_t)moff(mi) * C + 8 * q) = __builtin_convertvector(v, x4);
+                else if (!DBG(4) || v[0] == 12345.f) *reinterpret_cast<x4*>(trow + (int64_t)moff(mi) * C + 8 * q) = __builtin_convertvector(v, x4);
             }
             if constexpr (EPI) {
 #pragma unroll
@@ -406,15 +418,19 @@ template <int C, int W, int MT, int DT>
 int launch_t16(const T16K& k, bool next, int64_t n_px, hipStream_t stream) {
     using K = T16Cfg<C, W, MT>;
     static bool attr_set = false;
+    static int pad = 0;
     if (!attr_set) {
-        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)trunk16_kernel<C, W, MT, DT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES));
-        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)trunk16_kernel<C, W, MT, DT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES));
+#ifdef VQAE_T16_TRACE
+        pad = getenv("VQAE_T16_LDS_PAD") ? atoi(getenv("VQAE_T16_LDS_PAD")) : 0;      // experiment: fewer workgroups per CU
+#endif
+        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)trunk16_kernel<C, W, MT, DT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES + pad));
+        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)trunk16_kernel<C, W, MT, DT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES + pad));
         attr_set = true;
     }
     const int n_tiles = (int)(n_px / (32 * MT));
     vqae::ProfScope prof(C >= 128 && W == 32 ? vqae::PROF_CONV3X3_TRUNK : 0, stream, 2.0 * (double)n_px * C * (9.0 * C + C + (next ? C : 0)));
-    if (next) trunk16_kernel<C, W, MT, DT, true><<<n_tiles, K::NT, K::LDS_BYTES, stream>>>(k);
-    else trunk16_kernel<C, W, MT, DT, false><<<n_tiles, K::NT, K::LDS_BYTES, stream>>>(k);
+    if (next) trunk16_kernel<C, W, MT, DT, true><<<n_tiles, K::NT, K::LDS_BYTES + pad, stream>>>(k);
+    else trunk16_kernel<C, W, MT, DT, false><<<n_tiles, K::NT, K::LDS_BYTES + pad, stream>>>(k);
     prof.done();
     VQAE_LAUNCH_CHECK();
     return VQAE_OK;
@@ -493,6 +509,9 @@ int trunk16_block(const void* t1, const void* w2f, const void* w3f, float act_a,
 }  // namespace vqae
 
 #ifdef VQAE_T16_TRACE
+extern "C" int vqae_debug_t16_dbg(int bits) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_t16_dbg), &bits, sizeof(bits)) == hipSuccess ? 0 : -3;
+}
 extern "C" int vqae_debug_t16_trace(void* dev_buf) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_t16_trace), &dev_buf, sizeof(dev_buf)) == hipSuccess ? 0 : -3;
 }

@@ -69,69 +69,104 @@ void down_block_kernel(const DownK p) {
     };
 
     // ---- phase 1: conv1 on the 2 ROWS x 64 input pixels -> T1 ----------------------------------------------------------
+    // A wave owns PGW groups of 32 consecutive input pixels.  ALL their rows are requested before anything is computed
+    // (8 x 16 B per lane, 64 KiB per CU with two workgroups): this is the launch's HBM read, and with one load in flight
+    // per wave -- the first version -- the block ran at 1.4 TB/s, bound by latency x bytes in flight, not bandwidth.
     float* const T1 = lds;
-#pragma unroll 1
-    for (int item = wave; item < (TPX / 8) * NT; item += 4) {
-        const int pg = item / NT, ct = item % NT;      // 32-pixel group of an input row, output-channel tile
+    constexpr int PGW = TPX / 8 / 4;                  // 4, 2, 1 pixel groups per wave
+    constexpr int KU = CI / 8;                        // k-slices of conv1
+    f32x4 xin[PGW][KU];
+#pragma unroll
+    for (int i = 0; i < PGW; ++i) {
+        const int pg = wave * PGW + i;
         const int irow = pg >> 1, ix = (pg & 1) * 32 + li;
         const float* src = xim + ((int64_t)(2 * oy0 + irow) * p.W + 2 * ox0 + ix) * CI + 4 * hh;
-        f32x16 acc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int u = 0; u < KU; ++u) xin[i][u] = *reinterpret_cast<const f32x4*>(src + 8 * u);
+    }
+    f32x4 wf[2][KU];                                  // conv1 weight fragments of one channel tile, the next tile's in flight
 #pragma unroll
-        for (int u = 0; u < CI / 8; ++u) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(src + 8 * u);
-            const f32x4 wv = wfrag(p.w1, CI / 8, ct, u);
+    for (int u = 0; u < KU; ++u) wf[0][u] = wfrag(p.w1, KU, 0, u);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = rnd(elu_act(v[e] + p.b1a) + p.b1b);            // conv1 input cast
+    for (int i = 0; i < PGW; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[r], v[r], acc, 0, 0, 0);   // D[channel][pixel]
+        for (int u = 0; u < KU; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xin[i][u][e] = rnd(elu_act(xin[i][u][e] + p.b1a) + p.b1b);   // conv1 input cast
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) {
+        if (ct + 1 < NT) {
+#pragma unroll
+            for (int u = 0; u < KU; ++u) wf[(ct + 1) & 1][u] = wfrag(p.w1, KU, ct + 1, u);
         }
-        float* dst = T1 + ((irow >> 1) * 32 + (ix >> 1)) * LD1 + ((irow & 1) * 2 + (ix & 1)) * CO + 32 * ct + 4 * hh;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 o;
+        for (int i = 0; i < PGW; ++i) {
+            const int pg = wave * PGW + i;
+            const int irow = pg >> 1, ix = (pg & 1) * 32 + li;
+            f32x16 acc;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = rnd(elu_act(rnd(acc[4 * g + e]) + p.b2a) + p.b2b);   // conv1 output / conv2 input casts
-            *reinterpret_cast<f32x4*>(dst + 8 * g) = o;
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int u = 0; u < KU; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[ct & 1][u][r], xin[i][u][r], acc, 0, 0, 0);   // D[channel][pixel]
+            float* dst = T1 + ((irow >> 1) * 32 + (ix >> 1)) * LD1 + ((irow & 1) * 2 + (ix & 1)) * CO + 32 * ct + 4 * hh;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rnd(elu_act(rnd(acc[4 * g + e]) + p.b2a) + p.b2b);   // conv1 output / conv2 input casts
+                *reinterpret_cast<f32x4*>(dst + 8 * g) = o;
+            }
         }
     }
-    __syncthreads();
 
     // ---- phase 2: conv2 (K = 4 CO) from T1; phase 3 operands -------------------------------------------------------------
     const int pg2 = wave / NT, ct = wave % NT;         // this wave's 32 output pixels and 32 output channels
     const int px = 32 * pg2 + li;                       // output pixel within the tile
     const int oy = oy0 + (px >> 5), ox = ox0 + (px & 31);
+    // skip_conv operands (the 2x2 input patches, L2 hits: phase 1 just read them) requested ahead of conv2
+    constexpr int KSK = 4 * CI / 8;
+    constexpr int SKB = KSK < 16 ? KSK : 16;           // loads in flight per lane
+    auto sk_addr = [&](int u) {
+        const int tap = u / (CI / 8), s_ = u % (CI / 8);
+        return xim + ((int64_t)(2 * oy + (tap >> 1)) * p.W + 2 * ox + (tap & 1)) * CI + 8 * s_ + 4 * hh;
+    };
+    f32x4 xs[SKB];
+#pragma unroll
+    for (int u = 0; u < SKB; ++u) xs[u] = *reinterpret_cast<const f32x4*>(sk_addr(u));
+    constexpr int KS2 = 4 * CO / 8;
+    constexpr int WR = 4;                               // conv2 weight fragments in flight (L2 round trip ~ 2 k-slices of MFMAs)
+    f32x4 wq[WR];
+#pragma unroll
+    for (int u = 0; u < WR; ++u) wq[u] = wfrag(p.w2, KS2, ct, u);
+    vqae::lds_barrier();                                // T1 complete (LDS-only barrier: the loads above stay in flight)
     f32x16 acc2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
     {
         const float* a0 = T1 + px * LD1 + 4 * hh;
-        constexpr int KS = 4 * CO / 8;
-        f32x4 wq[2], aq[2];
-        wq[0] = wfrag(p.w2, KS, ct, 0);
+        f32x4 aq[2];
         aq[0] = *reinterpret_cast<const f32x4*>(a0);
 #pragma unroll
-        for (int u = 0; u < KS; ++u) {
-            if (u + 1 < KS) {
-                wq[(u + 1) & 1] = wfrag(p.w2, KS, ct, u + 1);
-                aq[(u + 1) & 1] = *reinterpret_cast<const f32x4*>(a0 + 8 * (u + 1));
-            }
+        for (int u = 0; u < KS2; ++u) {
+            const f32x4 wv = wq[u % WR];
+            if (u + WR < KS2) wq[u % WR] = wfrag(p.w2, KS2, ct, u + WR);
+            if (u + 1 < KS2) aq[(u + 1) & 1] = *reinterpret_cast<const f32x4*>(a0 + 8 * (u + 1));
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[u & 1][r], aq[u & 1][r], acc2, 0, 0, 0);
+            for (int r = 0; r < 4; ++r) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[r], aq[u & 1][r], acc2, 0, 0, 0);
         }
     }
-    // skip_conv (K = 4 CI) straight from global while the other waves finish conv2
+    // skip_conv (K = 4 CI) while the other waves finish conv2
     f32x16 accs;
 #pragma unroll
     for (int r = 0; r < 16; ++r) accs[r] = 0.f;
     {
-        constexpr int KS = 4 * CI / 8;
 #pragma unroll
-        for (int u = 0; u < KS; ++u) {
-            const int tap = u / (CI / 8), s = u % (CI / 8);
-            f32x4 v = *reinterpret_cast<const f32x4*>(xim + ((int64_t)(2 * oy + (tap >> 1)) * p.W + 2 * ox + (tap & 1)) * CI + 8 * s + 4 * hh);
-            const f32x4 wv = wfrag(p.wsk, KS, ct, u);
+        for (int u = 0; u < KSK; ++u) {
+            f32x4 v = xs[u % SKB];
+            if (u + SKB < KSK) xs[u % SKB] = *reinterpret_cast<const f32x4*>(sk_addr(u + SKB));
+            const f32x4 wv = wfrag(p.wsk, KSK, ct, u);
             v = v + p.b1c;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = rnd(v[e]);                                   // skip_conv input cast

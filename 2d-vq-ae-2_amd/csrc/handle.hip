@@ -41,6 +41,10 @@ int fixup_conv1(const float* x, const float* w1f, float pa, float pb, float aa, 
                 hipStream_t stream);
 bool down_block_supported(int cin, int h, int w);
 int frag_weight_rect(const float* w_packed_dev, int n_rows, int K, float* out_dev, hipStream_t stream);
+size_t down16_weight_bytes(int n_rows, int K);
+int down16_pack_weight(const float* w_packed_dev, int n_rows, int K, int dtype, void* out_dev, hipStream_t stream);
+int down16_block(const float* x, const void* w1h, const void* w2h, const void* w3h, const void* wskh, int B, int H, int W,
+                 int cin, const float* scalars10, int dtype, float* y, hipStream_t stream);
 int down_block(const float* x, const float* w1f, const float* w2f, const float* w3f, const float* wskf, int B, int H, int W,
                int cin, const float* scalars10, int dtype, float* y, hipStream_t stream);
 bool up_tail_supported(int cb, int co);
@@ -109,6 +113,7 @@ struct Block {
     float *w1f = nullptr, *w3f = nullptr; // conv1 / conv3 weights in MFMA fragment order for the fused tails (both trunk kernels)
     float *w2f = nullptr, *wskf = nullptr;// 'down' blocks: conv2 / skip_conv in fragment order too (down_fused.hip)
     void *w1h = nullptr, *w2h = nullptr, *w3h = nullptr;   // 16-bit modes: conv1 / conv2 / conv3 as 16-bit MFMA fragments (trunk16.hip)
+    void *dw1h = nullptr, *dw2h = nullptr, *dw3h = nullptr, *dwskh = nullptr;   // 16-bit modes, 'down' blocks (down16.hip)
     // MBConv (conv_block.py:240-321), BatchNorms folded: br = expanded width, w2 = depthwise taps [k*k][br]
     int kind = VQAE_BLOCK_FIXUP, hidden = 0;
     float *bv1 = nullptr, *bv2 = nullptr, *bv3 = nullptr;                        // folded BN shifts
@@ -143,6 +148,7 @@ struct vqae_handle {
     bool t1_ready = false;                 // buf[1] already holds the current block's t1
     bool up_conv_first = true;             // fp32 up blocks: 1x1 convs before the bicubic resize (they commute)
     bool fuse_down = true;                 // 'down' blocks with 16/32/64 input channels: one launch (down_fused.hip)
+    bool fuse_down16 = true;               // ... on the 16-bit MFMA in the autocast modes (down16.hip)
     bool fuse_up_tail = true;              // fp32 up blocks at the stem-side levels: resize + ELU + conv3 + skip in one launch
     bool use_wino = true;                  // fp32 trunk blocks (C = 128 on a 32-wide grid, C = 64 on a 64-wide one): Winograd F(2x2,3x3) conv2
     void* idx_scratch = nullptr;           // indices nobody asked for (vqae_forward with idx == NULL)
@@ -279,6 +285,14 @@ int load_block(vqae_handle* h, const TensorMap& tm, const std::string& pre, int 
             if ((rc = dev_alloc(h, (size_t)cout * e.K * 4, &f))) return rc;
             *e.dst = (float*)f;
             if ((rc = vqae::frag_weight_rect(e.src, cout, e.K, *e.dst, nullptr))) return rc;
+        }
+        if (h->cfg.compute_dtype != VQAE_DT_F32 && h->fuse_down16) {     // 16-bit MFMA form (down16.hip)
+            struct { float* src; int K; void** dst; } m16[4] = {{b->w1, cin, &b->dw1h}, {b->w2, 4 * cout, &b->dw2h},
+                                                                {b->w3, cout, &b->dw3h}, {b->wskip, 4 * cin, &b->dwskh}};
+            for (auto& e : m16) {
+                if ((rc = dev_alloc(h, vqae::down16_weight_bytes(cout, e.K), e.dst))) return rc;
+                if ((rc = vqae::down16_pack_weight(e.src, cout, e.K, h->cfg.compute_dtype, *e.dst, nullptr))) return rc;
+            }
         }
         VQAE_HIP_CHECK(hipDeviceSynchronize());
     }
@@ -490,7 +504,9 @@ int run_block(vqae_handle* h, const Block& b, const Block* next, int B, int& H, 
     }
     if (b.mode == MODE_DOWN && b.w2f && vqae::down_block_supported(b.cin, H, W)) {
         const float sc[10] = {b.b1a, b.b1b, b.b2a, b.b2b, b.b3a, b.b3b, b.b4, b.scale, b.b1c, b.b1d};
-        if ((rc = vqae::down_block(X, b.w1f, b.w2f, b.w3f, b.wskf, B, H, W, b.cin, sc, g_dt, R, st))) return rc;
+        if (b.dw2h && g_dt != VQAE_DT_F32) {
+            if ((rc = vqae::down16_block(X, b.dw1h, b.dw2h, b.dw3h, b.dwskh, B, H, W, b.cin, sc, g_dt, R, st))) return rc;
+        } else if ((rc = vqae::down_block(X, b.w1f, b.w2f, b.w3f, b.wskf, B, H, W, b.cin, sc, g_dt, R, st))) return rc;
         H /= 2; W /= 2;
         std::swap(h->buf[0], h->buf[3]);
         return VQAE_OK;
@@ -747,6 +763,7 @@ extern "C" int vqae_create(const vqae_config* cfg, const vqae_tensor* tensors, i
     h->use_wino = !(getenv("VQAE_NO_WINOGRAD") && atoi(getenv("VQAE_NO_WINOGRAD")));
     h->fuse_up_tail = !(getenv("VQAE_NO_UP_TAIL_FUSION") && atoi(getenv("VQAE_NO_UP_TAIL_FUSION")));
     h->fuse_down = !(getenv("VQAE_NO_DOWN_FUSION") && atoi(getenv("VQAE_NO_DOWN_FUSION")));
+    h->fuse_down16 = !(getenv("VQAE_NO_DOWN16") && atoi(getenv("VQAE_NO_DOWN16")));
     h->fuse_vq = !(getenv("VQAE_NO_VQ_FUSION") && atoi(getenv("VQAE_NO_VQ_FUSION")));
     h->C = cfg->stem << cfg->n_down;
     h->D = cfg->projection_dim > 0 ? cfg->projection_dim : h->C;

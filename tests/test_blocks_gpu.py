@@ -212,3 +212,31 @@ def test_mid_models_end_to_end_vs_reference(amd, oracle, name, tag):
         assert agree >= 0.999 and rel <= 1e-9
     else:
         assert agree >= 0.97 and rel <= (2e-3 if tag == "bf16" else 1e-4)
+
+
+@pytest.mark.parametrize("tag", ["bf16", "f16"])
+@pytest.mark.parametrize("name", ["mid", "mid16", "midA"])
+def test_down16_equals_fp32_mfma_form_on_identical_inputs(amd, oracle, name, tag, monkeypatch):
+    """The 16-bit-MFMA 'down' block kernel (down16.hip) against the fp32-MFMA form with compiled-in cast points
+    (down_fused.hip, VQAE_NO_DOWN16=1) on identical inputs: both multiply the same 16-bit-rounded operands exactly and
+    accumulate in fp32, so they differ only where the summation order moves an fp32 sum across a 16-bit rounding
+    boundary (isolated flips): per-block bars."""
+    spec, p, x, taps = oracle_taps(oracle, name, tag)
+    nat16 = amd.NativeVQAE(amd.SPECS[name], p, compute_dtype=tag)
+    monkeypatch.setenv("VQAE_NO_DOWN16", "1")
+    nat32 = amd.NativeVQAE(amd.SPECS[name], p, compute_dtype=tag)
+    monkeypatch.delenv("VQAE_NO_DOWN16")
+    blocks = oracle.encoder_blocks(spec)
+    ins = [taps["stem"]] + [taps[b[0]] for b in blocks[:-1]]
+    n = 0
+    for i, (prefix, mode, ci, co) in enumerate(blocks):
+        if mode != "down":
+            continue
+        xin = nhwc(ins[i]).cuda()
+        a, b = nat16.run_blocks("encoder", i, 1, xin), nat32.run_blocks("encoder", i, 1, xin)
+        ok, rel, frac = compare(a, b.permute(0, 3, 1, 2).cpu(), tag, 1)
+        record_parity("down16_vs_fp32_mfma", model=name, dtype=tag, block=prefix, cin=ci, rel_err=rel, frac_off=frac)
+        assert ok, (prefix, ci, rel, frac)
+        assert not torch.equal(a, torch.zeros_like(a))
+        n += 1
+    assert n >= 2

@@ -33,6 +33,9 @@ bool trunk16_supported(int c, int h, int w, int dtype);
 size_t trunk16_weight_bytes(int c, int taps);
 int trunk16_pack_weight(const float* w_packed_dev, int c, int taps, int dtype, void* out_dev, hipStream_t stream);
 int trunk16_round_pack(const float* src, void* dst, int64_t n, int dtype, hipStream_t stream);
+bool trunk16_head_supported(int c, int64_t m, int dtype);
+int trunk16_head(const float* x, const void* w1f, float b1a, float b1b, float b2a, float b2b, void* t1, int64_t m, int c,
+                 int dtype, hipStream_t stream);
 int trunk16_block(const void* t1, const void* w2f, const void* w3f, float act_a, float act_b, float t_scale, float t_b4,
                   float* xio, const void* w1nf, float n_b1a, float n_b1b, float n_b2a, float n_b2b, void* t1_next,
                   int batch, int h, int w, int c, int dtype, hipStream_t stream);
@@ -437,7 +440,9 @@ int run_block(vqae_handle* h, const Block& b, const Block* next, int B, int& H, 
     int rc;
     if (b.mode == MODE_SAME && b.w2h && h->fuse_trunk && vqae::trunk16_supported(b.cin, H, W, g_dt)) {
         // 16-bit modes, C = 64 / 128 / 256 (trunk16.hip): t1 travels as 16-bit; one launch per block
-        if (!h->t1_ready) {                          // chain head: conv1 by the generic kernel (fp32 out), then the conv2 input cast
+        if (!h->t1_ready && vqae::trunk16_head_supported(b.cin, (int64_t)B * H * W, g_dt)) {   // chain head: its own conv1 launch
+            if ((rc = vqae::trunk16_head(X, b.w1h, b.b1a, b.b1b, b.b2a, b.b2b, P, (int64_t)B * H * W, b.cin, g_dt, st))) return rc;
+        } else if (!h->t1_ready) {                   // ... or the generic kernel (fp32 out) + the conv2 input cast
             ConvCall c1(B, H, W, b.cin, b.br, 1, 1, 0, VQAE_PAD_NONE);
             c1.pre(VQAE_PRE_BIAS_ELU_BIAS, b.b1a, b.b1b).act(b.b2a, b.b2b);
             if ((rc = vqae_conv2d_f32(&c1.a, X, b.w1, nullptr, nullptr, Q, st))) return rc;

@@ -26,6 +26,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 using vqae::elu_act;
@@ -405,6 +406,90 @@ __global__ void pack16_kernel(const float* __restrict__ w, int c, int taps, EL* 
     out[i] = (EL)w[(int64_t)n * taps * c + tap * c + k];              // rows >= c (c = 16) are the packed layout's zero padding
 }
 
+// conv1 of the block at the HEAD of a chain (the others get theirs from the previous block's launch), 16-bit modes:
+//   t1 = round16(ELU(round16(conv1x1(round16(ELU(x + b1a) + b1b))) + b2a) + b2b),   x fp32 [M][C] -> t1 16-bit [M][C]
+// A streaming launch (4 + 2 bytes per channel and pixel): no LDS tile, a wave takes G groups of 32 consecutive pixels per
+// trip of a grid-stride loop -- lane (pixel, k half) loads its 8 channels per k-step straight from global, the weights
+// (fragment order, <= 32 KiB; C <= 128) are the MFMA row operand from LDS, and the lane stores the 4 consecutive
+// channels of each register quad as 8 bytes.  The next trip's rows are requested before this trip's MFMAs.
+// (Before: the generic fp32 conv launch + a separate rounding pass -- 0.62 + 0.27 ms at C = 16 on 256 x 256, batch 256.)
+template <int C, int DT>
+__global__ __launch_bounds__(256)
+void head16_kernel(const float* __restrict__ x, const void* __restrict__ w1f, float b1a, float b1b, float b2a, float b2b,
+                   void* __restrict__ t1, int n_groups) {
+    using E = E16<DT>;
+    using x8 = typename E::x8;
+    using x4 = typename E::x4;
+    constexpr int KU = C / 16, NT = C < 32 ? 1 : C / 32, NQ = C >= 32 ? 4 : C / 8;
+    constexpr int G = C <= 16 ? 4 : (C <= 32 ? 2 : 1);             // 32-pixel groups per wave and trip (8+ x 16 B per lane in flight)
+    constexpr bool WLDS = true;                                     // weights staged in LDS (<= 32 KiB)
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int li = lane & 31, hh = lane >> 5;
+    if constexpr (WLDS) {
+        for (int i = tid; i < NT * KU * 64; i += 256) reinterpret_cast<u32x4*>(lds)[i] = reinterpret_cast<const u32x4*>(w1f)[i];
+        __syncthreads();
+    }
+    auto wfrag = [&](int ct, int u) -> x8 {
+        if constexpr (WLDS) return *reinterpret_cast<const x8*>(lds + ((ct * KU + u) * 64 + lane) * 16);
+        else return *reinterpret_cast<const x8*>((const char*)w1f + ((int64_t)(ct * KU + u) * 64 + lane) * 16);
+    };
+    const int wave_g = (blockIdx.x * 4 + (tid >> 6)) * G;           // first group of this wave's first trip
+    const int stride = gridDim.x * 4 * G;
+    f32x4 xin[G][KU][2];
+    auto load = [&](int g0) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int g = g0 + i < n_groups ? g0 + i : n_groups - 1;
+            const float* src = x + ((int64_t)g * 32 + li) * C + 8 * hh;
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                xin[i][u][0] = *reinterpret_cast<const f32x4*>(src + 16 * u);
+                xin[i][u][1] = *reinterpret_cast<const f32x4*>(src + 16 * u + 4);
+            }
+        }
+    };
+    constexpr bool AHEAD = C <= 64;                                 // wider rows: the register budget goes to one trip's operands
+    if (AHEAD && wave_g < n_groups) load(wave_g);
+    for (int g0 = wave_g; g0 < n_groups; g0 += stride) {
+        if (!AHEAD) load(g0);
+        x8 xa[G][KU];
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                f32x8 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = elu_act(xin[i][u][0][e] + b1a) + b1b;
+                    v[4 + e] = elu_act(xin[i][u][1][e] + b1a) + b1b;
+                }
+                xa[i][u] = __builtin_convertvector(v, x8);          // conv1 input cast
+            }
+        if (AHEAD && g0 + stride < n_groups) load(g0 + stride);     // next trip's rows, under this trip's MFMAs and stores
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            if (g0 + i >= n_groups) break;
+            typename E::elem* const dst = (typename E::elem*)t1 + ((int64_t)(g0 + i) * 32 + li) * C + 4 * hh;
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int u = 0; u < KU; ++u) acc = E::mma(wfrag(ct, u), xa[i][u], acc);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = elu_act(E::rnd(acc[4 * q + e]) + b2a) + b2b;   // conv1 output cast
+                    *reinterpret_cast<x4*>(dst + 32 * ct + 8 * q) = __builtin_convertvector(o, x4);   // conv2 input cast
+                }
+            }
+        }
+    }
+}
+
 template <typename EL>
 __global__ void round_pack16_kernel(const float* __restrict__ src, EL* __restrict__ dst, int64_t n4) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -477,6 +562,41 @@ int trunk16_pack_weight(const float* w_packed_dev, int c, int taps, int dtype, v
     else pack16_kernel<_Float16><<<(unsigned)ceil_div(n, 256), 256, 0, stream>>>(w_packed_dev, c, taps, (_Float16*)out_dev);
     VQAE_LAUNCH_CHECK();
     return VQAE_OK;
+}
+
+// chain-head conv1 (head16_kernel): x fp32 [M][c] -> t1 16-bit [M][c]; w1f from trunk16_pack_weight(.., taps = 1); M % 32 == 0
+bool trunk16_head_supported(int c, int64_t m, int dtype) {
+    static const bool off = getenv("VQAE_NO_T16_HEAD") && atoi(getenv("VQAE_NO_T16_HEAD"));
+    if (off || (dtype != VQAE_DT_BF16 && dtype != VQAE_DT_F16)) return false;
+    return (c == 16 || c == 32 || c == 64 || c == 128) && m > 0 && m % 32 == 0 && m / 32 < (1ll << 31);   // C = 256: generic conv + cast
+}
+
+template <int C, int DT>
+static int launch_head16(const float* x, const void* w1f, float b1a, float b1b, float b2a, float b2b, void* t1, int64_t m,
+                         hipStream_t stream) {
+    constexpr int KU = C / 16, NT = C < 32 ? 1 : C / 32, G = C <= 16 ? 4 : (C <= 32 ? 2 : 1);
+    constexpr int lds_bytes = C <= 128 ? NT * KU * 1024 : 0;
+    const int n_groups = (int)(m / 32);
+    const int64_t wgs = ceil_div(n_groups, 4 * G);
+    const unsigned grid = (unsigned)(wgs < 2048 ? wgs : 2048);      // 8 workgroups per CU; the rest by grid stride
+    head16_kernel<C, DT><<<grid, 256, lds_bytes, stream>>>(x, w1f, b1a, b1b, b2a, b2b, t1, n_groups);
+    VQAE_LAUNCH_CHECK();
+    return VQAE_OK;
+}
+
+int trunk16_head(const float* x, const void* w1f, float b1a, float b1b, float b2a, float b2b, void* t1, int64_t m, int c,
+                 int dtype, hipStream_t stream) {
+    VQAE_REQUIRE(x && w1f && t1, VQAE_ERR_INVALID, "trunk16_head: null pointer");
+    VQAE_REQUIRE(trunk16_head_supported(c, m, dtype), VQAE_ERR_UNSUPPORTED, "trunk16_head: C = %d, M = %lld, dtype %d", c, (long long)m, dtype);
+#define VQAE_H16(C_) (dtype == VQAE_DT_BF16 ? launch_head16<C_, VQAE_DT_BF16>(x, w1f, b1a, b1b, b2a, b2b, t1, m, stream) \
+                                            : launch_head16<C_, VQAE_DT_F16>(x, w1f, b1a, b1b, b2a, b2b, t1, m, stream))
+    switch (c) {
+        case 16: return VQAE_H16(16);
+        case 32: return VQAE_H16(32);
+        case 64: return VQAE_H16(64);
+        default: return VQAE_H16(128);
+    }
+#undef VQAE_H16
 }
 
 // fp32 [n] (n % 4 == 0) -> 16-bit, RNE: t1 of a chain head produced by the generic conv1 launch

@@ -10,7 +10,8 @@
 // the stem-side level = 0.5 ms of matrix pipe at 157 TFLOP/s: MFMA-bound at 1.1 ms).  On the 16-bit MFMA the same work is
 // 18 instructions per wave and tile, and the block is what it should be: one read of x (fp32) and one write of out.
 //
-// A 256-thread workgroup owns TPX = 4096 / CO output pixels (4, 2 or 1 output rows of 32) and their 2x2 input patches.
+// A 256-thread workgroup owns TPX = 4096 / max(CO, 32) output pixels (4, 4, 2 or 1 output rows of 32 for CI = 8 .. 64) and
+// their 2x2 input patches.
 // Weights are the MFMA row operand (fragment order, 1 KiB wave-wide loads from L2), so a lane holds 4 consecutive channels
 // of one pixel per register quad.  t1 / t2 live in LDS as 16-bit -- the values autocast has already rounded:
 //   phase 1  conv1 on the 4 TPX input pixels, rows from global (all of a wave's loads requested up front: the launch's
@@ -66,9 +67,11 @@ void down16_kernel(const Down16K p) {
     using x8 = typename E::x8;
     using x4 = typename E::x4;
     constexpr int CO = 2 * CI;
-    constexpr int TPX = 4096 / CO;                    // output pixels per workgroup
+    constexpr int COP = CO < 32 ? 32 : CO;            // MFMA rows (CI = 8: 16 channels + 16 zero rows of the packed weights)
+    constexpr int TPX = 4096 / COP;                   // output pixels per workgroup
     constexpr int ROWS = TPX / 32;                    // output rows per workgroup
-    constexpr int NT = CO / 32;                       // 32-channel output tiles
+    constexpr int NT = COP / 32;                      // 32-channel output tiles
+    constexpr int NQ = CO >= 32 ? 4 : CO / 8;         // register quads of a lane that hold real channels (8 g + 4 hh ..)
     constexpr int PS1 = 4 * CO * 2 + 16;              // T1 bytes per output pixel (odd number of 16-B slots: conflict-free b128 reads)
     constexpr int PS2 = CO * 2 + 16;                  // T2
     extern __shared__ __attribute__((aligned(16))) char lds[];       // T1[TPX][PS1] | T2[TPX][PS2]
@@ -98,7 +101,8 @@ void down16_kernel(const Down16K p) {
     // ---- phase 1: conv1 on the 2 ROWS x 64 input pixels -> T1 ------------------------------------------------------------
     // a wave owns PGW groups of 32 consecutive input pixels; lane (li, hh) holds channels 16 u + 8 hh .. + 8 of pixel li
     constexpr int PGW = TPX / 8 / 4;                  // 4, 2, 1
-    constexpr int KU = CI / 16;                       // k-steps of conv1
+    constexpr int KU = CI < 16 ? 1 : CI / 16;         // k-steps of conv1 (CI = 8: K padded to 16 with zero weights; lanes hh = 1 idle)
+    const bool kvalid = CI >= 16 || hh == 0;
     f32x4 xin[PGW][KU][2];
 #pragma unroll
     for (int i = 0; i < PGW; ++i) {
@@ -107,8 +111,8 @@ void down16_kernel(const Down16K p) {
         const float* src = xim + ((int64_t)(2 * oy0 + irow) * p.W + 2 * ox0 + ix) * CI + 8 * hh;
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
-            xin[i][u][0] = *reinterpret_cast<const f32x4*>(src + 16 * u);
-            xin[i][u][1] = *reinterpret_cast<const f32x4*>(src + 16 * u + 4);
+            xin[i][u][0] = kvalid ? *reinterpret_cast<const f32x4*>(src + 16 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
+            xin[i][u][1] = kvalid ? *reinterpret_cast<const f32x4*>(src + 16 * u + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
     x8 w1f[NT][KU];
@@ -139,7 +143,7 @@ void down16_kernel(const Down16K p) {
 #pragma unroll
             for (int u = 0; u < KU; ++u) acc = E::mma(w1f[ct][u], xa[u], acc);             // D[channel][pixel]
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
+            for (int g = 0; g < NQ; ++g) {
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = elu_act(E::rnd(acc[4 * g + e]) + p.b2a) + p.b2b;   // conv1 output cast
@@ -154,9 +158,10 @@ void down16_kernel(const Down16K p) {
     const int oy = oy0 + (px >> 5), ox = ox0 + (px & 31);
     constexpr int KSK = 4 * CI / 16;
     constexpr int SKB = KSK < 8 ? KSK : 8;             // skip k-steps in flight per lane (2 x 16 B each)
-    auto sk_addr = [&](int u) {
-        const int tap = u / (CI / 16), s_ = u % (CI / 16);
-        return xim + ((int64_t)(2 * oy + (tap >> 1)) * p.W + 2 * ox + (tap & 1)) * CI + 16 * s_ + 8 * hh;
+    auto sk_addr = [&](int u) {                         // k = 16 u + 8 hh + j = tap * CI + c
+        const int kk = 16 * u + 8 * hh;
+        const int tap = kk / CI, c0 = kk % CI;
+        return xim + ((int64_t)(2 * oy + (tap >> 1)) * p.W + 2 * ox + (tap & 1)) * CI + c0;
     };
     f32x4 xs[SKB][2];
 #pragma unroll
@@ -165,7 +170,7 @@ void down16_kernel(const Down16K p) {
         xs[u][1] = *reinterpret_cast<const f32x4*>(sk_addr(u) + 4);
     }
     constexpr int KS2 = 4 * CO / 16;
-    constexpr int WR = 4;                               // conv2 weight fragments in flight
+    constexpr int WR = KS2 < 4 ? KS2 : 4;              // conv2 weight fragments in flight
     x8 wq[WR];
 #pragma unroll
     for (int u = 0; u < WR; ++u) wq[u] = wfrag(p.w2, KS2, ct, u);
@@ -188,7 +193,7 @@ void down16_kernel(const Down16K p) {
     {
         char* const dst = T2 + px * PS2 + (32 * ct + 4 * hh) * 2;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < NQ; ++g) {
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = elu_act(E::rnd(acc2[4 * g + e]) + p.b3a) + p.b3b;     // conv2 output cast
@@ -227,7 +232,7 @@ void down16_kernel(const Down16K p) {
     }
     float* out = p.y + ((b * Ho + oy) * Wo + ox) * CO + 32 * ct + 4 * hh;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    for (int g = 0; g < NQ; ++g) {
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -239,22 +244,23 @@ void down16_kernel(const Down16K p) {
     }
 }
 
-// packed fp32 [n_rows][K] (already rounded to the 16-bit type) -> fragment order [n_rows/32][K/16][64 lanes][8]:
+// packed fp32 [>= n_rows][k_src] (vqae_conv_pack_weight_f32: rows beyond cout are zero; already rounded to the 16-bit
+// type) -> fragment order [n_rows/32][K/16][64 lanes][8], K = k_src rounded up to 16 with zeros:
 // lane (r, h) of k-step ks holds w[32 nt + r][16 ks + 8 h + j], j = 0..7
 template <typename EL>
-__global__ void pack16_rect_kernel(const float* __restrict__ w, int n_rows, int K, EL* __restrict__ out) {
+__global__ void pack16_rect_kernel(const float* __restrict__ w, int n_rows, int k_src, int K, EL* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)n_rows * K) return;
     const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
     const int64_t st = i >> 9;
     const int ks = (int)(st % (K / 16)), nt = (int)(st / (K / 16));
     const int n = nt * 32 + (lane & 31), k = ks * 16 + 8 * (lane >> 5) + j;
-    out[i] = (EL)w[(int64_t)n * K + k];
+    out[i] = k < k_src ? (EL)w[(int64_t)n * k_src + k] : (EL)0.f;
 }
 
 template <int CI, int DT>
 int launch_down16(const Down16K& k, int64_t n_tiles, hipStream_t stream) {
-    constexpr int CO = 2 * CI, TPX = 4096 / CO;
+    constexpr int CO = 2 * CI, TPX = 4096 / (CO < 32 ? 32 : CO);
     constexpr int lds_bytes = TPX * ((4 * CO * 2 + 16) + (CO * 2 + 16));
     static bool attr_set = false;
     if (!attr_set) {
@@ -270,17 +276,27 @@ int launch_down16(const Down16K& k, int64_t n_tiles, hipStream_t stream) {
 
 namespace vqae {
 
-bool down_block_supported(int cin, int h, int w);       // down_fused.hip: same tiling
+// cin in {8, 16, 32, 64}; output width a multiple of 32, output height a multiple of the tile's rows (4, 4, 2, 1)
+bool down16_supported(int cin, int h, int w) {
+    if (cin != 8 && cin != 16 && cin != 32 && cin != 64) return false;
+    const int rows = (4096 / (2 * cin < 32 ? 32 : 2 * cin)) / 32;
+    return h % 2 == 0 && w % 64 == 0 && (h / 2) % rows == 0;
+}
 
-size_t down16_weight_bytes(int n_rows, int K) { return (size_t)n_rows * K * 2; }
+static int pad_rows(int n) { return n < 32 ? 32 : n; }
+static int pad_k(int k) { return (k + 15) / 16 * 16; }
 
-// packed [n_rows][K] fp32 (device) -> 16-bit fragment order (device); n_rows % 32 == 0, K % 16 == 0
+size_t down16_weight_bytes(int n_rows, int K) { return (size_t)pad_rows(n_rows) * pad_k(K) * 2; }
+
+// packed [>= max(n_rows, 32)][K] fp32 (device; vqae_conv_pack_weight_f32 pads the rows to 128 with zeros) -> 16-bit fragment
+// order (device); n_rows % 32 == 0 or n_rows == 16; K % 8 == 0 (padded to 16 with zeros)
 int down16_pack_weight(const float* w_packed_dev, int n_rows, int K, int dtype, void* out_dev, hipStream_t stream) {
-    VQAE_REQUIRE(n_rows % 32 == 0 && K % 16 == 0, VQAE_ERR_INVALID, "down16_pack_weight: %d x %d", n_rows, K);
+    VQAE_REQUIRE((n_rows % 32 == 0 || n_rows == 16) && K % 8 == 0, VQAE_ERR_INVALID, "down16_pack_weight: %d x %d", n_rows, K);
     VQAE_REQUIRE(dtype == VQAE_DT_BF16 || dtype == VQAE_DT_F16, VQAE_ERR_INVALID, "down16_pack_weight: dtype %d", dtype);
-    const int64_t n = (int64_t)n_rows * K;
-    if (dtype == VQAE_DT_BF16) pack16_rect_kernel<__bf16><<<(unsigned)ceil_div(n, 256), 256, 0, stream>>>(w_packed_dev, n_rows, K, (__bf16*)out_dev);
-    else pack16_rect_kernel<_Float16><<<(unsigned)ceil_div(n, 256), 256, 0, stream>>>(w_packed_dev, n_rows, K, (_Float16*)out_dev);
+    const int nr = pad_rows(n_rows), kp = pad_k(K);
+    const int64_t n = (int64_t)nr * kp;
+    if (dtype == VQAE_DT_BF16) pack16_rect_kernel<__bf16><<<(unsigned)ceil_div(n, 256), 256, 0, stream>>>(w_packed_dev, nr, K, kp, (__bf16*)out_dev);
+    else pack16_rect_kernel<_Float16><<<(unsigned)ceil_div(n, 256), 256, 0, stream>>>(w_packed_dev, nr, K, kp, (_Float16*)out_dev);
     VQAE_LAUNCH_CHECK();
     return VQAE_OK;
 }
@@ -292,17 +308,18 @@ int down16_block(const float* x, const void* w1h, const void* w2h, const void* w
     if (B == 0) return VQAE_OK;
     VQAE_REQUIRE(dtype == VQAE_DT_BF16 || dtype == VQAE_DT_F16, VQAE_ERR_INVALID, "down16_block: dtype %d", dtype);
     VQAE_REQUIRE(x && w1h && w2h && w3h && wskh && y && scalars10, VQAE_ERR_INVALID, "down16_block: null pointer");
-    VQAE_REQUIRE(down_block_supported(cin, H, W), VQAE_ERR_UNSUPPORTED, "down16_block: cin %d, %dx%d", cin, H, W);
+    VQAE_REQUIRE(down16_supported(cin, H, W), VQAE_ERR_UNSUPPORTED, "down16_block: cin %d, %dx%d", cin, H, W);
     Down16K k;
     k.x = x; k.w1 = w1h; k.w2 = w2h; k.w3 = w3h; k.wsk = wskh; k.y = y;
     k.H = H; k.W = W;
-    const int rows = (4096 / (2 * cin)) / 32;
+    const int rows = (4096 / (2 * cin < 32 ? 32 : 2 * cin)) / 32;
     k.tiles_x = (W / 2) / 32; k.tiles_y = (H / 2) / rows;
     k.b1a = scalars10[0]; k.b1b = scalars10[1]; k.b2a = scalars10[2]; k.b2b = scalars10[3]; k.b3a = scalars10[4];
     k.b3b = scalars10[5]; k.b4 = scalars10[6]; k.scale = scalars10[7]; k.b1c = scalars10[8]; k.b1d = scalars10[9];
     const int64_t n_tiles = (int64_t)B * k.tiles_x * k.tiles_y;
     VQAE_REQUIRE(n_tiles < (1ll << 31), VQAE_ERR_UNSUPPORTED, "down16_block: too many tiles");
 #define VQAE_D16(CI_) (dtype == VQAE_DT_BF16 ? launch_down16<CI_, VQAE_DT_BF16>(k, n_tiles, stream) : launch_down16<CI_, VQAE_DT_F16>(k, n_tiles, stream))
+    if (cin == 8) return VQAE_D16(8);
     if (cin == 16) return VQAE_D16(16);
     if (cin == 32) return VQAE_D16(32);
     return VQAE_D16(64);

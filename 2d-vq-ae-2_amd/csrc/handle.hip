@@ -44,6 +44,7 @@ int fixup_conv1(const float* x, const float* w1f, float pa, float pb, float aa, 
                 hipStream_t stream);
 bool down_block_supported(int cin, int h, int w);
 int frag_weight_rect(const float* w_packed_dev, int n_rows, int K, float* out_dev, hipStream_t stream);
+bool down16_supported(int cin, int h, int w);
 size_t down16_weight_bytes(int n_rows, int K);
 int down16_pack_weight(const float* w_packed_dev, int n_rows, int K, int dtype, void* out_dev, hipStream_t stream);
 int down16_block(const float* x, const void* w1h, const void* w2h, const void* w3h, const void* wskh, int B, int H, int W,
@@ -289,13 +290,15 @@ int load_block(vqae_handle* h, const TensorMap& tm, const std::string& pre, int 
             *e.dst = (float*)f;
             if ((rc = vqae::frag_weight_rect(e.src, cout, e.K, *e.dst, nullptr))) return rc;
         }
-        if (h->cfg.compute_dtype != VQAE_DT_F32 && h->fuse_down16) {     // 16-bit MFMA form (down16.hip)
-            struct { float* src; int K; void** dst; } m16[4] = {{b->w1, cin, &b->dw1h}, {b->w2, 4 * cout, &b->dw2h},
-                                                                {b->w3, cout, &b->dw3h}, {b->wskip, 4 * cin, &b->dwskh}};
-            for (auto& e : m16) {
-                if ((rc = dev_alloc(h, vqae::down16_weight_bytes(cout, e.K), e.dst))) return rc;
-                if ((rc = vqae::down16_pack_weight(e.src, cout, e.K, h->cfg.compute_dtype, *e.dst, nullptr))) return rc;
-            }
+        VQAE_HIP_CHECK(hipDeviceSynchronize());
+    }
+    if (mode == MODE_DOWN && cout == 2 * cin && h->cfg.compute_dtype != VQAE_DT_F32 && h->fuse_down16 &&
+        (cin == 8 || cin == 16 || cin == 32 || cin == 64)) {             // 16-bit MFMA form of the whole block (down16.hip)
+        struct { float* src; int K; void** dst; } m16[4] = {{b->w1, cin, &b->dw1h}, {b->w2, 4 * cout, &b->dw2h},
+                                                            {b->w3, cout, &b->dw3h}, {b->wskip, 4 * cin, &b->dwskh}};
+        for (auto& e : m16) {
+            if ((rc = dev_alloc(h, vqae::down16_weight_bytes(cout, e.K), e.dst))) return rc;
+            if ((rc = vqae::down16_pack_weight(e.src, cout, e.K, h->cfg.compute_dtype, *e.dst, nullptr))) return rc;
         }
         VQAE_HIP_CHECK(hipDeviceSynchronize());
     }
@@ -507,11 +510,16 @@ int run_block(vqae_handle* h, const Block& b, const Block* next, int B, int& H, 
         c3.scale_bias(b.scale, b.b4);
         return vqae_conv2d_f32(&c3.a, Q, b.w3, nullptr, X, X, st);          // + inp, in place
     }
+    if (b.mode == MODE_DOWN && b.dw2h && g_dt != VQAE_DT_F32 && vqae::down16_supported(b.cin, H, W)) {
+        const float sc[10] = {b.b1a, b.b1b, b.b2a, b.b2b, b.b3a, b.b3b, b.b4, b.scale, b.b1c, b.b1d};
+        if ((rc = vqae::down16_block(X, b.dw1h, b.dw2h, b.dw3h, b.dwskh, B, H, W, b.cin, sc, g_dt, R, st))) return rc;
+        H /= 2; W /= 2;
+        std::swap(h->buf[0], h->buf[3]);
+        return VQAE_OK;
+    }
     if (b.mode == MODE_DOWN && b.w2f && vqae::down_block_supported(b.cin, H, W)) {
         const float sc[10] = {b.b1a, b.b1b, b.b2a, b.b2b, b.b3a, b.b3b, b.b4, b.scale, b.b1c, b.b1d};
-        if (b.dw2h && g_dt != VQAE_DT_F32) {
-            if ((rc = vqae::down16_block(X, b.dw1h, b.dw2h, b.dw3h, b.dwskh, B, H, W, b.cin, sc, g_dt, R, st))) return rc;
-        } else if ((rc = vqae::down_block(X, b.w1f, b.w2f, b.w3f, b.wskf, B, H, W, b.cin, sc, g_dt, R, st))) return rc;
+        if ((rc = vqae::down_block(X, b.w1f, b.w2f, b.w3f, b.wskf, B, H, W, b.cin, sc, g_dt, R, st))) return rc;
         H /= 2; W /= 2;
         std::swap(h->buf[0], h->buf[3]);
         return VQAE_OK;

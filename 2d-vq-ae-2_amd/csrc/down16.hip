@@ -289,9 +289,9 @@ static int pad_k(int k) { return (k + 15) / 16 * 16; }
 size_t down16_weight_bytes(int n_rows, int K) { return (size_t)pad_rows(n_rows) * pad_k(K) * 2; }
 
 // packed [>= max(n_rows, 32)][K] fp32 (device; vqae_conv_pack_weight_f32 pads the rows to 128 with zeros) -> 16-bit fragment
-// order (device); n_rows % 32 == 0 or n_rows == 16; K % 8 == 0 (padded to 16 with zeros)
+// order (device); n_rows % 32 == 0 or n_rows in {8, 16}; K % 8 == 0 (padded to 16 with zeros)
 int down16_pack_weight(const float* w_packed_dev, int n_rows, int K, int dtype, void* out_dev, hipStream_t stream) {
-    VQAE_REQUIRE((n_rows % 32 == 0 || n_rows == 16) && K % 8 == 0, VQAE_ERR_INVALID, "down16_pack_weight: %d x %d", n_rows, K);
+    VQAE_REQUIRE((n_rows % 32 == 0 || n_rows == 16 || n_rows == 8) && K % 8 == 0, VQAE_ERR_INVALID, "down16_pack_weight: %d x %d", n_rows, K);
     VQAE_REQUIRE(dtype == VQAE_DT_BF16 || dtype == VQAE_DT_F16, VQAE_ERR_INVALID, "down16_pack_weight: dtype %d", dtype);
     const int nr = pad_rows(n_rows), kp = pad_k(K);
     const int64_t n = (int64_t)nr * kp;

@@ -35,7 +35,10 @@ int trunk16_pack_weight(const float* w_packed_dev, int c, int taps, int dtype, v
 int trunk16_round_pack(const float* src, void* dst, int64_t n, int dtype, hipStream_t stream);
 bool trunk16_head_supported(int c, int64_t m, int dtype);
 int trunk16_head(const float* x, const void* w1f, float b1a, float b1b, float b2a, float b2b, void* t1, int64_t m, int c,
-                 int dtype, hipStream_t stream);
+                 int dtype, bool out32, hipStream_t stream);
+bool up16_supported(int c, int h, int w, int dtype);
+int up16_block(const float* x, const float* t1, const void* w2h, const void* w3h, const void* wskh, int B, int H, int W, int c,
+               float b3a, float b3b, float scale, float b4, float b1c, float b1d, int dtype, float* y, hipStream_t stream);
 int trunk16_block(const void* t1, const void* w2f, const void* w3f, float act_a, float act_b, float t_scale, float t_b4,
                   float* xio, const void* w1nf, float n_b1a, float n_b1b, float n_b2a, float n_b2b, void* t1_next,
                   int batch, int h, int w, int c, int dtype, hipStream_t stream);
@@ -118,6 +121,7 @@ struct Block {
     float *w2f = nullptr, *wskf = nullptr;// 'down' blocks: conv2 / skip_conv in fragment order too (down_fused.hip)
     void *w1h = nullptr, *w2h = nullptr, *w3h = nullptr;   // 16-bit modes: conv1 / conv2 / conv3 as 16-bit MFMA fragments (trunk16.hip)
     void *dw1h = nullptr, *dw2h = nullptr, *dw3h = nullptr, *dwskh = nullptr;   // 16-bit modes, 'down' blocks (down16.hip)
+    void *uw1h = nullptr, *uw2h = nullptr, *uw3h = nullptr, *uwskh = nullptr;   // 16-bit modes, 'up' blocks (head16 + up16.hip)
     // MBConv (conv_block.py:240-321), BatchNorms folded: br = expanded width, w2 = depthwise taps [k*k][br]
     int kind = VQAE_BLOCK_FIXUP, hidden = 0;
     float *bv1 = nullptr, *bv2 = nullptr, *bv3 = nullptr;                        // folded BN shifts
@@ -153,6 +157,7 @@ struct vqae_handle {
     bool up_conv_first = true;             // fp32 up blocks: 1x1 convs before the bicubic resize (they commute)
     bool fuse_down = true;                 // 'down' blocks with 16/32/64 input channels: one launch (down_fused.hip)
     bool fuse_down16 = true;               // ... on the 16-bit MFMA in the autocast modes (down16.hip)
+    bool fuse_up16 = true;                 // 'up' blocks in the autocast modes: head16 + one launch (up16.hip)
     bool fuse_up_tail = true;              // fp32 up blocks at the stem-side levels: resize + ELU + conv3 + skip in one launch
     bool use_wino = true;                  // fp32 trunk blocks (C = 128 on a 32-wide grid, C = 64 on a 64-wide one): Winograd F(2x2,3x3) conv2
     void* idx_scratch = nullptr;           // indices nobody asked for (vqae_forward with idx == NULL)
@@ -302,6 +307,17 @@ int load_block(vqae_handle* h, const TensorMap& tm, const std::string& pre, int 
         }
         VQAE_HIP_CHECK(hipDeviceSynchronize());
     }
+    if (mode == MODE_UP && cin == 2 * cout && h->cfg.compute_dtype != VQAE_DT_F32 && h->fuse_up16 &&
+        (cin == 16 || cin == 32 || cin == 64 || cin == 128)) {            // 16-bit MFMA form: head16 (conv1) + up16.hip (the rest)
+        if ((rc = dev_alloc(h, vqae::trunk16_weight_bytes(cin, 1), &b->uw1h))) return rc;
+        if ((rc = vqae::trunk16_pack_weight(b->w1, cin, 1, h->cfg.compute_dtype, b->uw1h, nullptr))) return rc;
+        struct { float* src; int rows; void** dst; } mu[3] = {{b->w2, cin, &b->uw2h}, {b->w3, cout, &b->uw3h}, {b->wskip, cout, &b->uwskh}};
+        for (auto& e : mu) {
+            if ((rc = dev_alloc(h, vqae::down16_weight_bytes(e.rows, cin), e.dst))) return rc;
+            if ((rc = vqae::down16_pack_weight(e.src, e.rows, cin, h->cfg.compute_dtype, *e.dst, nullptr))) return rc;
+        }
+        VQAE_HIP_CHECK(hipDeviceSynchronize());
+    }
 #undef S_
     return VQAE_OK;
 }
@@ -444,7 +460,7 @@ int run_block(vqae_handle* h, const Block& b, const Block* next, int B, int& H, 
     if (b.mode == MODE_SAME && b.w2h && h->fuse_trunk && vqae::trunk16_supported(b.cin, H, W, g_dt)) {
         // 16-bit modes, C = 64 / 128 / 256 (trunk16.hip): t1 travels as 16-bit; one launch per block
         if (!h->t1_ready && vqae::trunk16_head_supported(b.cin, (int64_t)B * H * W, g_dt)) {   // chain head: its own conv1 launch
-            if ((rc = vqae::trunk16_head(X, b.w1h, b.b1a, b.b1b, b.b2a, b.b2b, P, (int64_t)B * H * W, b.cin, g_dt, st))) return rc;
+            if ((rc = vqae::trunk16_head(X, b.w1h, b.b1a, b.b1b, b.b2a, b.b2b, P, (int64_t)B * H * W, b.cin, g_dt, false, st))) return rc;
         } else if (!h->t1_ready) {                   // ... or the generic kernel (fp32 out) + the conv2 input cast
             ConvCall c1(B, H, W, b.cin, b.br, 1, 1, 0, VQAE_PAD_NONE);
             c1.pre(VQAE_PRE_BIAS_ELU_BIAS, b.b1a, b.b1b).act(b.b2a, b.b2b);
@@ -572,6 +588,14 @@ int run_block(vqae_handle* h, const Block& b, const Block* next, int B, int& H, 
         ConvCall c3(B, H, W, b.br, b.cout, 1, 1, 0, VQAE_PAD_NONE);
         c3.pre(VQAE_PRE_BIAS_ELU_BIAS, b.b3a, b.b3b).scale_bias(b.scale, b.b4);
         if ((rc = vqae_conv2d_f32(&c3.a, P, b.w3, nullptr, R, R, st))) return rc;
+        std::swap(h->buf[0], h->buf[3]);
+        return VQAE_OK;
+    }
+    if (b.uw2h && vqae::up16_supported(b.cin, H, W, g_dt) && vqae::trunk16_head_supported(b.cin, (int64_t)B * H * W, g_dt)) {
+        // 16-bit modes: conv1 at the low resolution (fp32 result of the activation), then the whole high-resolution part in one launch
+        if ((rc = vqae::trunk16_head(X, b.uw1h, b.b1a, b.b1b, b.b2a, b.b2b, Q, (int64_t)B * H * W, b.cin, g_dt, true, st))) return rc;
+        if ((rc = vqae::up16_block(X, Q, b.uw2h, b.uw3h, b.uwskh, B, H, W, b.cin, b.b3a, b.b3b, b.scale, b.b4, b.b1c, b.b1d, g_dt, R, st))) return rc;
+        H *= 2; W *= 2;
         std::swap(h->buf[0], h->buf[3]);
         return VQAE_OK;
     }
@@ -777,6 +801,7 @@ extern "C" int vqae_create(const vqae_config* cfg, const vqae_tensor* tensors, i
     h->fuse_up_tail = !(getenv("VQAE_NO_UP_TAIL_FUSION") && atoi(getenv("VQAE_NO_UP_TAIL_FUSION")));
     h->fuse_down = !(getenv("VQAE_NO_DOWN_FUSION") && atoi(getenv("VQAE_NO_DOWN_FUSION")));
     h->fuse_down16 = !(getenv("VQAE_NO_DOWN16") && atoi(getenv("VQAE_NO_DOWN16")));
+    h->fuse_up16 = !(getenv("VQAE_NO_UP16") && atoi(getenv("VQAE_NO_UP16")));
     h->fuse_vq = !(getenv("VQAE_NO_VQ_FUSION") && atoi(getenv("VQAE_NO_VQ_FUSION")));
     h->C = cfg->stem << cfg->n_down;
     h->D = cfg->projection_dim > 0 ? cfg->projection_dim : h->C;

@@ -413,7 +413,8 @@ __global__ void pack16_kernel(const float* __restrict__ w, int c, int taps, EL* 
 // (fragment order, <= 32 KiB; C <= 128) are the MFMA row operand from LDS, and the lane stores the 4 consecutive
 // channels of each register quad as 8 bytes.  The next trip's rows are requested before this trip's MFMAs.
 // (Before: the generic fp32 conv launch + a separate rounding pass -- 0.62 + 0.27 ms at C = 16 on 256 x 256, batch 256.)
-template <int C, int DT>
+// OUT32: the fp32 value ELU(round16(conv1) + b2a) + b2b is stored as it is ('up' blocks: a bicubic resize, not a conv, reads it)
+template <int C, int DT, bool OUT32>
 __global__ __launch_bounds__(256)
 void head16_kernel(const float* __restrict__ x, const void* __restrict__ w1f, float b1a, float b1b, float b2a, float b2b,
                    void* __restrict__ t1, int n_groups) {
@@ -471,6 +472,7 @@ void head16_kernel(const float* __restrict__ x, const void* __restrict__ w1f, fl
         for (int i = 0; i < G; ++i) {
             if (g0 + i >= n_groups) break;
             typename E::elem* const dst = (typename E::elem*)t1 + ((int64_t)(g0 + i) * 32 + li) * C + 4 * hh;
+            float* const dst32 = (float*)t1 + ((int64_t)(g0 + i) * 32 + li) * C + 4 * hh;
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) {
                 f32x16 acc;
@@ -483,7 +485,8 @@ void head16_kernel(const float* __restrict__ x, const void* __restrict__ w1f, fl
                     f32x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = elu_act(E::rnd(acc[4 * q + e]) + b2a) + b2b;   // conv1 output cast
-                    *reinterpret_cast<x4*>(dst + 32 * ct + 8 * q) = __builtin_convertvector(o, x4);   // conv2 input cast
+                    if constexpr (OUT32) *reinterpret_cast<f32x4*>(dst32 + 32 * ct + 8 * q) = o;
+                    else *reinterpret_cast<x4*>(dst + 32 * ct + 8 * q) = __builtin_convertvector(o, x4);   // conv2 input cast
                 }
             }
         }
@@ -564,7 +567,7 @@ int trunk16_pack_weight(const float* w_packed_dev, int c, int taps, int dtype, v
     return VQAE_OK;
 }
 
-// chain-head conv1 (head16_kernel): x fp32 [M][c] -> t1 16-bit [M][c]; w1f from trunk16_pack_weight(.., taps = 1); M % 32 == 0
+// chain-head conv1 (head16_kernel): x fp32 [M][c] -> t1 16-bit [M][c] (out32: fp32, not rounded after the activation); w1f from trunk16_pack_weight(.., taps = 1); M % 32 == 0
 bool trunk16_head_supported(int c, int64_t m, int dtype) {
     static const bool off = getenv("VQAE_NO_T16_HEAD") && atoi(getenv("VQAE_NO_T16_HEAD"));
     if (off || (dtype != VQAE_DT_BF16 && dtype != VQAE_DT_F16)) return false;
@@ -573,23 +576,24 @@ bool trunk16_head_supported(int c, int64_t m, int dtype) {
 
 template <int C, int DT>
 static int launch_head16(const float* x, const void* w1f, float b1a, float b1b, float b2a, float b2b, void* t1, int64_t m,
-                         hipStream_t stream) {
+                         bool out32, hipStream_t stream) {
     constexpr int KU = C / 16, NT = C < 32 ? 1 : C / 32, G = C <= 16 ? 4 : (C <= 32 ? 2 : 1);
     constexpr int lds_bytes = C <= 128 ? NT * KU * 1024 : 0;
     const int n_groups = (int)(m / 32);
     const int64_t wgs = ceil_div(n_groups, 4 * G);
     const unsigned grid = (unsigned)(wgs < 2048 ? wgs : 2048);      // 8 workgroups per CU; the rest by grid stride
-    head16_kernel<C, DT><<<grid, 256, lds_bytes, stream>>>(x, w1f, b1a, b1b, b2a, b2b, t1, n_groups);
+    if (out32) head16_kernel<C, DT, true><<<grid, 256, lds_bytes, stream>>>(x, w1f, b1a, b1b, b2a, b2b, t1, n_groups);
+    else head16_kernel<C, DT, false><<<grid, 256, lds_bytes, stream>>>(x, w1f, b1a, b1b, b2a, b2b, t1, n_groups);
     VQAE_LAUNCH_CHECK();
     return VQAE_OK;
 }
 
 int trunk16_head(const float* x, const void* w1f, float b1a, float b1b, float b2a, float b2b, void* t1, int64_t m, int c,
-                 int dtype, hipStream_t stream) {
+                 int dtype, bool out32, hipStream_t stream) {
     VQAE_REQUIRE(x && w1f && t1, VQAE_ERR_INVALID, "trunk16_head: null pointer");
     VQAE_REQUIRE(trunk16_head_supported(c, m, dtype), VQAE_ERR_UNSUPPORTED, "trunk16_head: C = %d, M = %lld, dtype %d", c, (long long)m, dtype);
-#define VQAE_H16(C_) (dtype == VQAE_DT_BF16 ? launch_head16<C_, VQAE_DT_BF16>(x, w1f, b1a, b1b, b2a, b2b, t1, m, stream) \
-                                            : launch_head16<C_, VQAE_DT_F16>(x, w1f, b1a, b1b, b2a, b2b, t1, m, stream))
+#define VQAE_H16(C_) (dtype == VQAE_DT_BF16 ? launch_head16<C_, VQAE_DT_BF16>(x, w1f, b1a, b1b, b2a, b2b, t1, m, out32, stream) \
+                                            : launch_head16<C_, VQAE_DT_F16>(x, w1f, b1a, b1b, b2a, b2b, t1, m, out32, stream))
     switch (c) {
         case 16: return VQAE_H16(16);
         case 32: return VQAE_H16(32);

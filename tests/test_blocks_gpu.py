@@ -240,3 +240,29 @@ def test_down16_equals_fp32_mfma_form_on_identical_inputs(amd, oracle, name, tag
         assert not torch.equal(a, torch.zeros_like(a))
         n += 1
     assert n >= 2
+
+
+@pytest.mark.parametrize("tag", ["bf16", "f16"])
+@pytest.mark.parametrize("name", ["mid", "mid16", "midA"])
+def test_up16_equals_unfused_form_on_identical_inputs(amd, oracle, name, tag, monkeypatch):
+    """The fused 16-bit 'up' block (head16 conv1 + up16.hip: both resizes, conv2, conv3, skip_conv in one launch) against
+    the unfused form (VQAE_NO_UP16=1: fp32 bicubic launches + generic convs with cast points) on identical inputs.  Same
+    rounding points and the same resize arithmetic; only the convs' summation order differs: per-block bars."""
+    spec, p, x, taps = oracle_taps(oracle, name, tag)
+    fused = amd.NativeVQAE(amd.SPECS[name], p, compute_dtype=tag)
+    monkeypatch.setenv("VQAE_NO_UP16", "1")
+    plain = amd.NativeVQAE(amd.SPECS[name], p, compute_dtype=tag)
+    monkeypatch.delenv("VQAE_NO_UP16")
+    blocks = oracle.decoder_blocks(spec)
+    ins = [taps["q"]] + [taps[b[0]] for b in blocks[:-1]]
+    n = 0
+    for i, (prefix, mode, ci, co) in enumerate(blocks):
+        if mode != "up":
+            continue
+        xin = nhwc(ins[i]).cuda()
+        a, b = fused.run_blocks("decoder", i, 1, xin), plain.run_blocks("decoder", i, 1, xin)
+        ok, rel, frac = compare(a, b.permute(0, 3, 1, 2).cpu(), tag, 1)
+        record_parity("up16_vs_unfused", model=name, dtype=tag, block=prefix, cin=ci, rel_err=rel, frac_off=frac)
+        assert ok, (prefix, ci, rel, frac)
+        n += 1
+    assert n >= 2

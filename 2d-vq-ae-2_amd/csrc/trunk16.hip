@@ -61,12 +61,12 @@ struct T16K {
 };
 
 template <int C, int W, int MT> struct T16Cfg {
-    static_assert(MT == 2 || MT == 4, "m-tiles per workgroup");
+    static_assert(MT == 2 || MT == 4 || MT == 8 || MT == 16, "m-tiles per workgroup");
     static_assert(W == 32 || W == 64 || W == 128 || W == 256, "grid width");
     static_assert(C == 16 || C == 32 || C == 64 || C == 128 || C == 256, "channels");
     static constexpr int NW = C >= 32 ? C / 32 : 1;   // waves = 32-channel output slices (C = 16: one slice, half of it zero weights)
     static constexpr int NQ = C >= 32 ? 4 : C / 8;    // channel quads of a lane that exist (register quad q <-> channels 8 q + 4 h ..)
-    static constexpr int WM = C <= 32 ? MT : 1;       // wave groups along the pixels: with one channel slice (C <= 32) every m-tile
+    static constexpr int WM = C <= 32 ? (MT < 4 ? MT : 4) : 1;   // wave groups along the pixels: with one channel slice (C <= 32) every m-tile
     static constexpr int MTW = MT / WM;               //   gets its own wave (4x the waves, each 4x shorter); MTW = m-tiles per wave
     static constexpr int NT = NW * WM * 64;           // threads
     static constexpr int TW = W < 128 ? W : 128;      // columns a workgroup spans (wider grids: W / TW column blocks per row)
@@ -526,6 +526,7 @@ int launch_t16(const T16K& k, bool next, int64_t n_px, hipStream_t stream) {
 
 template <int DT>
 int launch_t16_cw(const T16K& k, bool next, int c, int w, int64_t n_px, hipStream_t stream) {
+    const int h_rows = k.H;
     // 4 m-tiles (128 pixels) per workgroup everywhere.  2 m-tiles (twice the resident workgroups) measured slower at
     // C = 128: every weight fragment then feeds 2 MFMAs instead of 4 and the kernel becomes bound by the L1 address path.
     if (c == 128 && w == 32) return launch_t16<128, 32, 4, DT>(k, next, n_px, stream);
@@ -533,6 +534,22 @@ int launch_t16_cw(const T16K& k, bool next, int c, int w, int64_t n_px, hipStrea
     if (c == 64 && w == 64) return launch_t16<64, 64, 4, DT>(k, next, n_px, stream);
     if (c == 128 && w == 64) return launch_t16<128, 64, 4, DT>(k, next, n_px, stream);
     if (c == 64 && w == 128) return launch_t16<64, 128, 4, DT>(k, next, n_px, stream);
+    // C <= 32: 16 m-tiles (512 pixels, 4 per wave) per workgroup where the rows allow it -- these levels are bound by the
+    // latency chain of a tile (stage -> conv2 -> conv3 -> conv1'), so more pixels per wave in flight is what pays
+    // (cfg A bf16 +3.3 %, cfg B f16 encode +2.9 % over 4 m-tiles; 8: +2.2 %).  VQAE_T16_MT = 4 / 8 / 16 overrides.
+    static const int mt_small = getenv("VQAE_T16_MT") ? atoi(getenv("VQAE_T16_MT")) : 16;
+    if (mt_small == 16 && h_rows % 4 == 0) {
+        if (c == 32 && w == 128) return launch_t16<32, 128, 16, DT>(k, next, n_px, stream);
+        if (c == 32 && w == 256) return launch_t16<32, 256, 16, DT>(k, next, n_px, stream);
+        if (c == 16 && w == 128) return launch_t16<16, 128, 16, DT>(k, next, n_px, stream);
+        if (c == 16 && w == 256) return launch_t16<16, 256, 16, DT>(k, next, n_px, stream);
+    }
+    if (mt_small == 8 && h_rows % 2 == 0) {
+        if (c == 32 && w == 128) return launch_t16<32, 128, 8, DT>(k, next, n_px, stream);
+        if (c == 32 && w == 256) return launch_t16<32, 256, 8, DT>(k, next, n_px, stream);
+        if (c == 16 && w == 128) return launch_t16<16, 128, 8, DT>(k, next, n_px, stream);
+        if (c == 16 && w == 256) return launch_t16<16, 256, 8, DT>(k, next, n_px, stream);
+    }
     if (c == 32 && w == 128) return launch_t16<32, 128, 4, DT>(k, next, n_px, stream);
     if (c == 32 && w == 256) return launch_t16<32, 256, 4, DT>(k, next, n_px, stream);
     if (c == 16 && w == 128) return launch_t16<16, 128, 4, DT>(k, next, n_px, stream);

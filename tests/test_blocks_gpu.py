@@ -266,3 +266,35 @@ def test_up16_equals_unfused_form_on_identical_inputs(amd, oracle, name, tag, mo
         assert ok, (prefix, ci, rel, frac)
         n += 1
     assert n >= 2
+
+
+@pytest.mark.parametrize("B,H,W", [(3, 128, 192), (1, 64, 256), (5, 192, 64)])
+@pytest.mark.parametrize("tag", ["bf16", "f16"])
+def test_16bit_down_up_kernels_on_odd_batches_and_non_square_inputs(amd, oracle, tag, B, H, W, monkeypatch):
+    """down16 / up16 / 512-pixel trunk16 tiles on shapes the fixtures do not have (odd batches, H != W, levels whose width is
+    not a multiple of the fused kernels' tile and therefore fall back to the generic launches in the middle of the model):
+    the default handle against one with the block fusions switched off, on the same input.  Encoder features and decoder
+    output: 16-bit chain bars (both are the same rounding-point arithmetic; flips cascade along the chain)."""
+    name = "mid16"
+    spec = oracle.SPECS[name]
+    p = oracle.make_params(spec, 0)
+    fused = amd.NativeVQAE(amd.SPECS[name], p, compute_dtype=tag)
+    for k in ("VQAE_NO_DOWN16", "VQAE_NO_UP16", "VQAE_NO_DOWN_FUSION"):
+        monkeypatch.setenv(k, "1")
+    plain = amd.NativeVQAE(amd.SPECS[name], p, compute_dtype=tag)
+    for k in ("VQAE_NO_DOWN16", "VQAE_NO_UP16", "VQAE_NO_DOWN_FUSION"):
+        monkeypatch.delenv(k)
+    x = oracle.make_patches(B, 256, 21)[:, :, :H, :W].contiguous().cuda()
+    z_f, z_p = fused.encode_features(x), plain.encode_features(x)
+    assert z_f.shape == z_p.shape and bool(torch.isfinite(z_f).all())
+    scale = float(z_p.abs().max())
+    e = (z_f - z_p).abs()
+    q = plain.encode(x)[0]
+    d_f, d_p = fused.decode(q), plain.decode(q)
+    ed = (d_f - d_p).abs()
+    dscale = float(d_p.abs().max())
+    record_parity("odd_geometry_16bit", dtype=tag, B=B, H=H, W=W, z_max_rel=float(e.max()) / scale, z_mean_rel=float(e.mean()) / scale,
+                  d_max_rel=float(ed.max()) / dscale, d_mean_rel=float(ed.mean()) / dscale)
+    n_blocks = 12
+    assert float(e.max()) <= 4 * ULP[tag] * scale * np.sqrt(n_blocks) and float(e.mean()) <= 0.5 * ULP[tag] * scale
+    assert float(ed.max()) <= 4 * ULP[tag] * dscale * np.sqrt(n_blocks) and float(ed.mean()) <= 0.5 * ULP[tag] * dscale

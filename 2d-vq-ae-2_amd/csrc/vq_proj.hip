@@ -161,22 +161,41 @@ void vq_proj_fused_kernel(const VqProjK p) {
             qr[j] = rnd16<DT>(z[j] + (ev - z[j]));
         }
     }
-    float* __restrict__ orow = p.out + row * p.C;
-#pragma unroll 2
-    for (int c = 0; c < p.C; c += 4) {
-        f32x4 o;
+    // Output rows: computed 2 rows per wave instruction, lane L -> row 2 i + (L >> 5), channels 4 (L & 31) .. + 3 of a 128-channel
+    // slab, so a store instruction writes two whole 512-byte row pieces.  (One row per lane -- 16 B per lane at a C * 4-byte
+    // stride, 64 line pieces per instruction -- made the stores cost more than everything else in the kernel.)  q of the
+    // row arrives by a cross-lane read; the fma chain per output is the one of the row-per-lane form, bit for bit.
+    const int lane = threadIdx.x & 63;
+    const int64_t row_w0 = (int64_t)blockIdx.x * VP_THREADS + (threadIdx.x & ~63);       // first row of this wave
+    for (int c0 = 0; c0 < p.C; c0 += 128) {
+        const int cl = c0 + 4 * (lane & 31);
+        const bool cvalid = cl < p.C;
+        const int cs = cvalid ? cl : 0;
+        f32x4 wv0[4], wv1[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const f32x4 w0 = *reinterpret_cast<const f32x4*>(s_wout + (c + e) * PD);
-            const f32x4 w1 = *reinterpret_cast<const f32x4*>(s_wout + (c + e) * PD + 4);
-            float a = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) a = __builtin_fmaf(qr[j], w0[j], a);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) a = __builtin_fmaf(qr[j + 4], w1[j], a);
-            o[e] = rnd16<DT>(a + s_bout[c + e]);
+            wv0[e] = *reinterpret_cast<const f32x4*>(s_wout + (cs + e) * PD);
+            wv1[e] = *reinterpret_cast<const f32x4*>(s_wout + (cs + e) * PD + 4);
         }
-        if (live) *reinterpret_cast<f32x4*>(orow + c) = o;
+        const f32x4 bo = *reinterpret_cast<const f32x4*>(s_bout + cs);
+#pragma unroll 4
+        for (int i = 0; i < 32; ++i) {
+            const int src = 2 * i + (lane >> 5);
+            float qs[PD];
+#pragma unroll
+            for (int j = 0; j < PD; ++j) qs[j] = __shfl(qr[j], src);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a = __builtin_fmaf(qs[j], wv0[e][j], a);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a = __builtin_fmaf(qs[j + 4], wv1[e][j], a);
+                o[e] = rnd16<DT>(a + bo[e]);
+            }
+            if (cvalid && row_w0 + src < p.N) *reinterpret_cast<f32x4*>(p.out + (row_w0 + src) * p.C + cl) = o;
+        }
     }
 }
 

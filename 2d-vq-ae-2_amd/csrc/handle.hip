@@ -36,6 +36,9 @@ int trunk16_round_pack(const float* src, void* dst, int64_t n, int dtype, hipStr
 bool trunk16_head_supported(int c, int64_t m, int dtype);
 int trunk16_head(const float* x, const void* w1f, float b1a, float b1b, float b2a, float b2b, void* t1, int64_t m, int c,
                  int dtype, bool out32, hipStream_t stream);
+bool same8_16_supported(int c, int h, int w, int dtype);
+int same8_16_block(const float* x, float* y, const float* w1_packed, const void* w2h, const void* w3h, int B, int H, int W,
+                   const float* scalars8, int dtype, hipStream_t stream);
 bool up16_supported(int c, int h, int w, int dtype);
 int up16_block(const float* x, const float* t1, const void* w2h, const void* w3h, const void* wskh, int B, int H, int W, int c,
                float b3a, float b3b, float scale, float b4, float b1c, float b1d, int dtype, float* y, hipStream_t stream);
@@ -122,6 +125,7 @@ struct Block {
     void *w1h = nullptr, *w2h = nullptr, *w3h = nullptr;   // 16-bit modes: conv1 / conv2 / conv3 as 16-bit MFMA fragments (trunk16.hip)
     void *dw1h = nullptr, *dw2h = nullptr, *dw3h = nullptr, *dwskh = nullptr;   // 16-bit modes, 'down' blocks (down16.hip)
     void *uw1h = nullptr, *uw2h = nullptr, *uw3h = nullptr, *uwskh = nullptr;   // 16-bit modes, 'up' blocks (head16 + up16.hip)
+    void *s8w2h = nullptr, *s8w3h = nullptr;                                    // 16-bit modes, C = 8 'same' blocks (same8_16.hip)
     // MBConv (conv_block.py:240-321), BatchNorms folded: br = expanded width, w2 = depthwise taps [k*k][br]
     int kind = VQAE_BLOCK_FIXUP, hidden = 0;
     float *bv1 = nullptr, *bv2 = nullptr, *bv3 = nullptr;                        // folded BN shifts
@@ -305,6 +309,12 @@ int load_block(vqae_handle* h, const TensorMap& tm, const std::string& pre, int 
             if ((rc = dev_alloc(h, vqae::down16_weight_bytes(cout, e.K), e.dst))) return rc;
             if ((rc = vqae::down16_pack_weight(e.src, cout, e.K, h->cfg.compute_dtype, *e.dst, nullptr))) return rc;
         }
+        VQAE_HIP_CHECK(hipDeviceSynchronize());
+    }
+    if (mode == MODE_SAME && cin == 8 && cout == 8 && h->cfg.compute_dtype != VQAE_DT_F32) {   // same8_16.hip
+        if ((rc = dev_alloc(h, vqae::down16_weight_bytes(8, 72), &b->s8w2h)) || (rc = dev_alloc(h, vqae::down16_weight_bytes(8, 8), &b->s8w3h))) return rc;
+        if ((rc = vqae::down16_pack_weight(b->w2, 8, 72, h->cfg.compute_dtype, b->s8w2h, nullptr))) return rc;
+        if ((rc = vqae::down16_pack_weight(b->w3, 8, 8, h->cfg.compute_dtype, b->s8w3h, nullptr))) return rc;
         VQAE_HIP_CHECK(hipDeviceSynchronize());
     }
     if (mode == MODE_UP && cin == 2 * cout && h->cfg.compute_dtype != VQAE_DT_F32 && h->fuse_up16 &&
@@ -508,6 +518,13 @@ int run_block(vqae_handle* h, const Block& b, const Block* next, int B, int& H, 
         return VQAE_OK;
     }
     h->t1_ready = false;
+    if (b.mode == MODE_SAME && b.s8w2h && g_dt != VQAE_DT_F32 && vqae::same8_16_supported(b.cin, H, W, g_dt)) {
+        // 16-bit modes, C = 8: the whole block on the 16-bit MFMA (csrc/same8_16.hip), X -> P, swap
+        const float sc[8] = {b.b1a, b.b1b, b.b2a, b.b2b, b.b3a, b.b3b, b.b4, b.scale};
+        if ((rc = vqae::same8_16_block(X, P, b.w1, b.s8w2h, b.s8w3h, B, H, W, sc, g_dt, st))) return rc;
+        std::swap(h->buf[0], h->buf[1]);
+        return VQAE_OK;
+    }
     if (b.mode == MODE_SAME && b.cin == b.cout && vqae_fixup_same_supported(b.cin, H, W)) {
         // high-resolution levels: the whole block in one launch (csrc/fixup_fused.hip), X -> P, swap
         const float sc[8] = {b.b1a, b.b1b, b.b2a, b.b2b, b.b3a, b.b3b, b.b4, b.scale};

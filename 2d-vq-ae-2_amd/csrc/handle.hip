@@ -40,7 +40,7 @@ bool same8_16_supported(int c, int h, int w, int dtype);
 int same8_16_block(const float* x, float* y, const float* w1_packed, const void* w2h, const void* w3h, int B, int H, int W,
                    const float* scalars8, int dtype, hipStream_t stream);
 bool same16_16_supported(int c, int h, int w, int dtype);
-int same16_16_block(const float* x, float* y, const void* w1h, const void* w2h, const void* w3h, int B, int H, int W,
+int same16_16_block(const float* x, float* y, const void* w1h, const void* w2h, const void* w3h, int B, int H, int W, int c,
                     const float* scalars8, int dtype, hipStream_t stream);
 bool up16_supported(int c, int h, int w, int dtype);
 int up16_block(const float* x, const float* t1, const void* w2h, const void* w3h, const void* wskh, int B, int H, int W, int c,
@@ -470,10 +470,10 @@ int run_block(vqae_handle* h, const Block& b, const Block* next, int B, int& H, 
     if (b.kind == VQAE_BLOCK_MBCONV) return run_mbconv(h, b, B, H, W, st);
     float *X = h->buf[0], *P = h->buf[1], *Q = h->buf[2], *R = h->buf[3];
     int rc;
-    if (b.mode == MODE_SAME && b.w2h && b.cin == 16 && h->fuse_trunk && vqae::same16_16_supported(b.cin, H, W, g_dt)) {
-        // 16-bit modes, C = 16: a whole block per launch (csrc/same8_16.hip) beats the chained trunk16 launches at this width
+    if (b.mode == MODE_SAME && b.w2h && h->fuse_trunk && vqae::same16_16_supported(b.cin, H, W, g_dt)) {
+        // 16-bit modes, C = 16 / 32: a whole block per launch (csrc/same8_16.hip) beats the chained trunk16 launches at these widths
         const float sc[8] = {b.b1a, b.b1b, b.b2a, b.b2b, b.b3a, b.b3b, b.b4, b.scale};
-        if ((rc = vqae::same16_16_block(X, P, b.w1h, b.w2h, b.w3h, B, H, W, sc, g_dt, st))) return rc;
+        if ((rc = vqae::same16_16_block(X, P, b.w1h, b.w2h, b.w3h, B, H, W, b.cin, sc, g_dt, st))) return rc;
         std::swap(h->buf[0], h->buf[1]);
         h->t1_ready = false;
         return VQAE_OK;

@@ -172,77 +172,94 @@ void same8_16_kernel(const S8K p) {
 //       {4 hh .. + 3, 8 + 4 hh .. + 3} -> activation -> t1 (32 B per pixel) in LDS
 //   P2  as the C = 8 form with one tap per k-step (9 steps), two register quads per lane, the lane halves swap one quad each.
 struct S16K {
-    const float* __restrict__ x;         // [B][H][W][16] fp32
+    const float* __restrict__ x;         // [B][H][W][C] fp32
     float* __restrict__ y;
-    const void* __restrict__ w1f;        // trunk16_pack_weight fragments: [32 rows (16 real)][16]
-    const void* __restrict__ w2f;        //   [32 (16)][9 * 16], k = tap * 16 + c
-    const void* __restrict__ w3f;        //   [32 (16)][16]
+    const void* __restrict__ w1f;        // trunk16_pack_weight fragments: [32 rows (C real)][C]
+    const void* __restrict__ w2f;        //   [32][9 * C], k = tap * C + c
+    const void* __restrict__ w3f;        //   [32][C]
     int H, W, tiles_x, tiles_y, n_tiles;
     float b1a, b1b, b2a, b2b, b3a, b3b, b4, scale;
 };
 
-template <int DT>
+// C = 16 or 32 (one 32-row n-tile).  Lane (pixel, hh) of a result holds NQ = C / 8 register quads: channels 8 q + 4 hh .. + 3.
+template <int C, int DT>
 __global__ __launch_bounds__(256)
-void same16_16_kernel(const S16K p) {
+void same_small16_kernel(const S16K p) {
     using E = S16<DT>;
     using x8 = typename E::x8;
     using x4 = typename E::x4;
-    __shared__ __attribute__((aligned(16))) char T1[S8_HP * 32];     // t1 of the halo, 16 x 16 bit per pixel
+    constexpr int KS = C / 16;                                            // k-steps of a 1x1 conv
+    constexpr int NQ = C / 8;
+    constexpr int PSX = C == 16 ? 32 : C * 2 + 16;                        // t1 bytes per halo pixel (C = 32: + one 16-B slot against bank conflicts)
+    __shared__ __attribute__((aligned(16))) char T1[S8_HP * PSX];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, hh = lane >> 5;
-    const x8 w1v = *reinterpret_cast<const x8*>((const char*)p.w1f + lane * 16);
-    x8 w2v[9];
+    x8 w1v[KS], w2v[9 * KS], w3v[KS];
 #pragma unroll
-    for (int u = 0; u < 9; ++u) w2v[u] = *reinterpret_cast<const x8*>((const char*)p.w2f + (u * 64 + lane) * 16);
-    const x8 w3v = *reinterpret_cast<const x8*>((const char*)p.w3f + lane * 16);
+    for (int u = 0; u < KS; ++u) {
+        w1v[u] = *reinterpret_cast<const x8*>((const char*)p.w1f + (u * 64 + lane) * 16);
+        w3v[u] = *reinterpret_cast<const x8*>((const char*)p.w3f + (u * 64 + lane) * 16);
+    }
+#pragma unroll
+    for (int u = 0; u < 9 * KS; ++u) w2v[u] = *reinterpret_cast<const x8*>((const char*)p.w2f + (u * 64 + lane) * 16);
 
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
         const int txi = tile % p.tiles_x;
         const int tyi = (tile / p.tiles_x) % p.tiles_y;
         const int b = tile / (p.tiles_x * p.tiles_y);
         const int ty0 = tyi * S8_TH, tx0 = txi * S8_TW;
-        const float* const xim = p.x + (int64_t)b * p.H * p.W * 16;
+        const float* const xim = p.x + (int64_t)b * p.H * p.W * C;
         // ---- P1: t1 on the halo, 32 pixels per wave and step -----------------------------------------------------------------------
         constexpr int NG = (S8_HP + 31) / 32;                              // 21 groups
         constexpr int NGW = (NG + 3) / 4;                                  // per wave (the last ones of waves 1..3 repeat group NG - 1)
-        f32x4 a0[NGW], a1[NGW];
+        constexpr int NGB = C == 16 ? NGW : 3;                             // groups whose rows are requested together (register budget)
 #pragma unroll
-        for (int it = 0; it < NGW; ++it) {                                 // every row of the halo requested up front
-            int g = wave + 4 * it;
-            g = g < NG ? g : NG - 1;
-            int hp = g * 32 + li;
-            hp = hp < S8_HP ? hp : S8_HP - 1;
-            const int hy = hp / S8_HC, hx = hp - S8_HC * hy;
-            int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
-            iy = iy < 0 ? iy + p.H : (iy >= p.H ? iy - p.H : iy);
-            ix = ix < 0 ? ix + p.W : (ix >= p.W ? ix - p.W : ix);
-            const f32x4* src = reinterpret_cast<const f32x4*>(xim + ((int64_t)iy * p.W + ix) * 16 + 8 * hh);
-            a0[it] = src[0];
-            a1[it] = src[1];
-        }
+        for (int it0 = 0; it0 < NGW; it0 += NGB) {
+            f32x4 av[NGB][KS][2];
 #pragma unroll
-        for (int it = 0; it < NGW; ++it) {
-            int g = wave + 4 * it;
-            g = g < NG ? g : NG - 1;
-            const int hp = g * 32 + li;
-            f32x8 v;
+            for (int j = 0; j < NGB; ++j) {
+                int g = wave + 4 * (it0 + j);
+                g = g < NG ? g : NG - 1;
+                int hp = g * 32 + li;
+                hp = hp < S8_HP ? hp : S8_HP - 1;
+                const int hy = hp / S8_HC, hx = hp - S8_HC * hy;
+                int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
+                iy = iy < 0 ? iy + p.H : (iy >= p.H ? iy - p.H : iy);
+                ix = ix < 0 ? ix + p.W : (ix >= p.W ? ix - p.W : ix);
+                const float* src = xim + ((int64_t)iy * p.W + ix) * C + 8 * hh;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[e] = elu_act(a0[it][e] + p.b1a) + p.b1b;
-                v[4 + e] = elu_act(a1[it][e] + p.b1a) + p.b1b;
+                for (int u = 0; u < KS; ++u) {
+                    av[j][u][0] = *reinterpret_cast<const f32x4*>(src + 16 * u);
+                    av[j][u][1] = *reinterpret_cast<const f32x4*>(src + 16 * u + 4);
+                }
             }
-            f32x16 acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            acc = E::mma(w1v, __builtin_convertvector(v, x8), acc);        // conv1 input cast
+            for (int j = 0; j < NGB; ++j) {
+                int g = wave + 4 * (it0 + j);
+                g = g < NG ? g : NG - 1;
+                const int hp = g * 32 + li;
+                f32x16 acc;
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                f32x4 t;
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) t[e] = elu_act(E::rnd(acc[4 * q + e]) + p.b2a) + p.b2b;     // conv1 output cast
-                if (hp < S8_HP) *reinterpret_cast<x4*>(T1 + hp * 32 + (8 * q + 4 * hh) * 2) = __builtin_convertvector(t, x4);   // conv2 input cast
+                for (int u = 0; u < KS; ++u) {
+                    f32x8 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = elu_act(av[j][u][0][e] + p.b1a) + p.b1b;
+                        v[4 + e] = elu_act(av[j][u][1][e] + p.b1a) + p.b1b;
+                    }
+                    acc = E::mma(w1v[u], __builtin_convertvector(v, x8), acc);    // conv1 input cast
+                }
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    f32x4 t;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = elu_act(E::rnd(acc[4 * q + e]) + p.b2a) + p.b2b;     // conv1 output cast
+                    if (hp < S8_HP) *reinterpret_cast<x4*>(T1 + hp * PSX + (8 * q + 4 * hh) * 2) = __builtin_convertvector(t, x4);   // conv2 input cast
+                }
             }
         }
         lds_barrier();
@@ -251,47 +268,54 @@ void same16_16_kernel(const S16K p) {
         for (int i = 0; i < 4; ++i) {
             const int mt = wave * 4 + i;
             const int py = mt >> 1, px = (mt & 1) * 32 + li;
-            const int64_t o = (((int64_t)b * p.H + ty0 + py) * p.W + tx0 + px) * 16 + 4 * hh;
-            const f32x4 res0 = *reinterpret_cast<const f32x4*>(p.x + o), res1 = *reinterpret_cast<const f32x4*>(p.x + o + 8);
+            const int64_t o = (((int64_t)b * p.H + ty0 + py) * p.W + tx0 + px) * C + 4 * hh;
+            f32x4 res[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) res[q] = *reinterpret_cast<const f32x4*>(p.x + o + 8 * q);
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-            for (int u = 0; u < 9; ++u) {
-                const int ty = u / 3, tx = u - 3 * ty;
-                acc = E::mma(w2v[u], *reinterpret_cast<const x8*>(T1 + ((py + ty) * S8_HC + px + tx) * 32 + 16 * hh), acc);
-            }
-            u32x2 qb[2];
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ty = tap / 3, tx = tap - 3 * ty;
+                const char* tp = T1 + ((py + ty) * S8_HC + px + tx) * PSX + 16 * hh;
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
+                for (int u = 0; u < KS; ++u) acc = E::mma(w2v[tap * KS + u], *reinterpret_cast<const x8*>(tp + 32 * u), acc);
+            }
+            u32x2 qb[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
                 f32x4 t2;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) t2[e] = elu_act(E::rnd(acc[4 * q + e]) + p.b3a) + p.b3b;   // conv2 output cast
                 qb[q] = __builtin_bit_cast(u32x2, __builtin_convertvector(t2, x4));                   // conv3 input cast
             }
-            // conv3 operand of lane half hh: channels 8 hh .. + 7.  Own quads: {4 hh .., 8 + 4 hh ..}: hh = 0 keeps quad 0 and
-            // receives the partner's quad 0 (channels 4..7); hh = 1 keeps quad 1 (12..15) and receives the partner's quad 1 (8..11)
-            const u32x2 send = hh == 0 ? qb[1] : qb[0];
-            u32x2 recv;
-            recv[0] = __shfl_xor(send[0], 32);
-            recv[1] = __shfl_xor(send[1], 32);
-            const u32x4 opb = hh == 0 ? u32x4{qb[0][0], qb[0][1], recv[0], recv[1]} : u32x4{recv[0], recv[1], qb[1][0], qb[1][1]};
+            // conv3 operand of k-step u, lane half hh: channels 16 u + 8 hh .. + 7.  Own quads hold {8 q + 4 hh ..}: hh = 0 keeps
+            // quad 2u (16u .. + 3) and receives the partner's quad 2u (16u + 4 ..); hh = 1 receives the partner's quad 2u + 1
+            // (16u + 8 ..) and keeps its own quad 2u + 1 (16u + 12 ..)
             f32x16 acc3;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc3[r] = 0.f;
-            acc3 = E::mma(w3v, __builtin_bit_cast(x8, opb), acc3);
-            f32x4 out0, out1;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float tv = E::rnd(acc3[e]) * p.scale;                      // conv3 output cast
-                tv = tv + p.b4;
-                out0[e] = tv + res0[e];
-                float tw = E::rnd(acc3[4 + e]) * p.scale;
-                tw = tw + p.b4;
-                out1[e] = tw + res1[e];
+            for (int u = 0; u < KS; ++u) {
+                const u32x2 send = hh == 0 ? qb[2 * u + 1] : qb[2 * u];
+                u32x2 recv;
+                recv[0] = __shfl_xor(send[0], 32);
+                recv[1] = __shfl_xor(send[1], 32);
+                const u32x4 opb = hh == 0 ? u32x4{qb[2 * u][0], qb[2 * u][1], recv[0], recv[1]} : u32x4{recv[0], recv[1], qb[2 * u + 1][0], qb[2 * u + 1][1]};
+                acc3 = E::mma(w3v[u], __builtin_bit_cast(x8, opb), acc3);
             }
-            *reinterpret_cast<f32x4*>(p.y + o) = out0;
-            *reinterpret_cast<f32x4*>(p.y + o + 8) = out1;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                f32x4 out;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float tv = E::rnd(acc3[4 * q + e]) * p.scale;          // conv3 output cast
+                    tv = tv + p.b4;
+                    out[e] = tv + res[q][e];
+                }
+                *reinterpret_cast<f32x4*>(p.y + o + 8 * q) = out;
+            }
         }
         lds_barrier();
     }
@@ -329,18 +353,19 @@ int same8_16_block(const float* x, float* y, const float* w1_packed, const void*
     return VQAE_OK;
 }
 
-// C = 16: x -> y (x != y), [B][H][W][16] fp32; w1h / w2h / w3h: trunk16_pack_weight(c = 16; taps 1 / 9 / 1)
+// C = 16 / 32: x -> y (x != y), [B][H][W][C] fp32; w1h / w2h / w3h: trunk16_pack_weight(c = C; taps 1 / 9 / 1)
 bool same16_16_supported(int c, int h, int w, int dtype) {
     static const bool off = getenv("VQAE_NO_SAME16_16") && atoi(getenv("VQAE_NO_SAME16_16"));
+    static const bool off32 = getenv("VQAE_NO_SAME32_16") && atoi(getenv("VQAE_NO_SAME32_16"));
     if (off || (dtype != VQAE_DT_BF16 && dtype != VQAE_DT_F16)) return false;
-    return c == 16 && h % S8_TH == 0 && w % S8_TW == 0;
+    return (c == 16 || (c == 32 && !off32)) && h % S8_TH == 0 && w % S8_TW == 0;
 }
 
-int same16_16_block(const float* x, float* y, const void* w1h, const void* w2h, const void* w3h, int B, int H, int W,
+int same16_16_block(const float* x, float* y, const void* w1h, const void* w2h, const void* w3h, int B, int H, int W, int c,
                     const float* scalars8, int dtype, hipStream_t stream) {
     if (B == 0) return VQAE_OK;
     VQAE_REQUIRE(x && y && x != y && w1h && w2h && w3h && scalars8, VQAE_ERR_INVALID, "same16_16_block: bad pointer");
-    VQAE_REQUIRE(same16_16_supported(16, H, W, dtype), VQAE_ERR_UNSUPPORTED, "same16_16_block: %dx%d, dtype %d", H, W, dtype);
+    VQAE_REQUIRE(same16_16_supported(c, H, W, dtype), VQAE_ERR_UNSUPPORTED, "same16_16_block: C = %d, %dx%d, dtype %d", c, H, W, dtype);
     S16K k;
     k.x = x; k.y = y; k.w1f = w1h; k.w2f = w2h; k.w3f = w3h;
     k.H = H; k.W = W; k.tiles_x = W / S8_TW; k.tiles_y = H / S8_TH;
@@ -350,8 +375,13 @@ int same16_16_block(const float* x, float* y, const void* w1h, const void* w2h, 
     k.b1a = scalars8[0]; k.b1b = scalars8[1]; k.b2a = scalars8[2]; k.b2b = scalars8[3];
     k.b3a = scalars8[4]; k.b3b = scalars8[5]; k.b4 = scalars8[6]; k.scale = scalars8[7];
     const unsigned grid = (unsigned)(n_tiles < 256 * 6 ? n_tiles : 256 * 6);
-    if (dtype == VQAE_DT_BF16) same16_16_kernel<VQAE_DT_BF16><<<grid, 256, 0, stream>>>(k);
-    else same16_16_kernel<VQAE_DT_F16><<<grid, 256, 0, stream>>>(k);
+    if (c == 16) {
+        if (dtype == VQAE_DT_BF16) same_small16_kernel<16, VQAE_DT_BF16><<<grid, 256, 0, stream>>>(k);
+        else same_small16_kernel<16, VQAE_DT_F16><<<grid, 256, 0, stream>>>(k);
+    } else {
+        if (dtype == VQAE_DT_BF16) same_small16_kernel<32, VQAE_DT_BF16><<<grid, 256, 0, stream>>>(k);
+        else same_small16_kernel<32, VQAE_DT_F16><<<grid, 256, 0, stream>>>(k);
+    }
     VQAE_LAUNCH_CHECK();
     return VQAE_OK;
 }

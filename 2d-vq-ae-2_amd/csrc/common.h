@@ -94,11 +94,11 @@ __device__ __forceinline__ float elu_act(float v) {
     const float e = __builtin_fmaf(sc, em, sc - 1.0f);
     return v > 0.f ? v : e;
 #else
-    // min(e - 1, 0) written as -clamp01(1 - e): the compiler folds the clamp into the subtract's output modifier
-    // (v_sub_f32 ... clamp), 5 instructions in all; same value bit for bit (e > 0, so the upper bound never binds)
+    // ELU(v) = median(v, e^v - 1, 0): for v >= 0, 0 <= v <= e^v - 1; for v < 0, v < e^v - 1 < 0 (e^v >= 1 + v).  Four
+    // instructions (v_mul, v_exp, v_add, v_med3) -- one fewer than max(v, 0) - clamp01(1 - e), same value bit for bit (e - 1 and
+    // -(1 - e) round alike).  The activation arithmetic is what bounds the small-channel 16-bit block kernels (PMC: vector issue).
     const float e = __builtin_amdgcn_exp2f(v * 1.44269504088896341f);
-    const float m = __builtin_fminf(__builtin_fmaxf(1.0f - e, 0.0f), 1.0f);
-    return fmaxf(v, 0.f) - m;
+    return __builtin_amdgcn_fmed3f(v, e - 1.0f, 0.0f);
 #endif
 }
 

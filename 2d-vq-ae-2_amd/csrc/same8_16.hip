@@ -61,7 +61,7 @@ constexpr int S8_TH = 8, S8_TW = 64;                     // output tile
 constexpr int S8_HC = S8_TW + 2, S8_HP = (S8_TH + 2) * S8_HC;   // halo columns / pixels
 
 template <int DT>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, 2)
 void same8_16_kernel(const S8K p) {
     using E = S16<DT>;
     using x8 = typename E::x8;
@@ -183,7 +183,7 @@ struct S16K {
 
 // C = 16 or 32 (one 32-row n-tile).  Lane (pixel, hh) of a result holds NQ = C / 8 register quads: channels 8 q + 4 hh .. + 3.
 template <int C, int DT>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, 2)                     // 2 waves per SIMD: a 256-register budget keeps the MFMA results in VGPRs (no v_accvgpr_read)
 void same_small16_kernel(const S16K p) {
     using E = S16<DT>;
     using x8 = typename E::x8;

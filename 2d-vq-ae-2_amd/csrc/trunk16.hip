@@ -415,7 +415,7 @@ __global__ void pack16_kernel(const float* __restrict__ w, int c, int taps, EL* 
 // (Before: the generic fp32 conv launch + a separate rounding pass -- 0.62 + 0.27 ms at C = 16 on 256 x 256, batch 256.)
 // OUT32: the fp32 value ELU(round16(conv1) + b2a) + b2b is stored as it is ('up' blocks: a bicubic resize, not a conv, reads it)
 template <int C, int DT, bool OUT32>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, 2)
 void head16_kernel(const float* __restrict__ x, const void* __restrict__ w1f, float b1a, float b1b, float b2a, float b2b,
                    void* __restrict__ t1, int n_groups) {
     using E = E16<DT>;

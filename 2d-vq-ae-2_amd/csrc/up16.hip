@@ -58,7 +58,7 @@ struct Up16K {
 };
 
 template <int C, int DT, int ROWS>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, 2)
 void up16_kernel(const Up16K p) {
     using E = U16<DT>;
     using x8 = typename E::x8;

@@ -45,8 +45,9 @@ __device__ __forceinline__ void merge_best(float& b1, int& i1, float& b2, float 
 __global__ __launch_bounds__(VQ_WAVES * 64)
 void vq_tier1_kernel(const float* __restrict__ z, const float* __restrict__ eT, int64_t N, int K, int Kpad,
                      int D, float thr, int* __restrict__ idx32, float* __restrict__ margin,
-                     int* __restrict__ flag_count, int* __restrict__ flag_list) {
+                     int* __restrict__ flag_count, int* __restrict__ flag_list, const int* __restrict__ run_if) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [<=VQ_TD][VQ_TK]
+    if (run_if && *run_if == 0) return;               // the matrix-pipe filter (vq_filter.hip) has done this launch
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
@@ -346,6 +347,7 @@ struct VqWorkspace {
     int* idx32;           // N
     double* partials;     // 1024
     float* eT;            // D * Kpad
+    void* ftab;           // vq_filter.hip's code-side operand table
 };
 
 inline VqWorkspace carve(void* ws, int64_t N, int K, int D) {
@@ -356,13 +358,18 @@ inline VqWorkspace carve(void* ws, int64_t N, int K, int D) {
     const int64_t Kpad = vqae::round_up(K, VQ_TK);
     w.eT = (float*)p; p += vqae::round_up((int64_t)D * Kpad * 4, 256);
     w.flag_list = (int*)p; p += vqae::round_up(N * 4, 256);
-    w.idx32 = (int*)p;
+    w.idx32 = (int*)p; p += vqae::round_up(N * 4, 256);
+    w.ftab = (void*)p;
     return w;
 }
 
 }  // namespace
 
 namespace vqae {
+bool vq_filter_supported(int K, int D);
+size_t vq_filter_table_bytes(int K, int D);
+int vq_filter_run(const float* z, const float* embed, int64_t N, int K, int D, float thr, int* idx32, int* flags, int* flag_list,
+                  void* table, hipStream_t stream);
 // shared with the fused projected quantiser (vq_proj.hip)
 int vq_tier2_run(const float* z, const float* embed, int K, int D, int* idx32, const int* flag_count, const int* flag_list,
                  hipStream_t stream) {
@@ -399,8 +406,9 @@ int vq_write_idx(const int* idx32, int64_t N, void* idx_out, int idx_dtype, hipS
 
 extern "C" size_t vqae_vq_workspace_bytes(int64_t n_rows, int n_codes, int dim) {
     const int64_t Kpad = vqae::round_up(n_codes, VQ_TK);
+    const size_t ftab = (dim == 256) ? (size_t)vqae::round_up((int64_t)vqae::vq_filter_table_bytes(n_codes, dim), 256) : 0;
     return (size_t)(256 + 1024 * sizeof(double) + vqae::round_up((int64_t)dim * Kpad * 4, 256) +
-                    2 * vqae::round_up(n_rows * 4, 256) + 256);
+                    2 * vqae::round_up(n_rows * 4, 256) + 256) + ftab;
 }
 
 extern "C" int vqae_vq_forward_f32(const float* z, const float* embed, int64_t N, int K, int D, float commitment,
@@ -436,11 +444,20 @@ extern "C" int vqae_vq_forward_f32(const float* z, const float* embed, int64_t N
         }
         // evaluation-noise bound between tier-1 sums and the reference recipe's sums
         const float thr = (4.0f * (float)D + 16.0f) * 5.9604645e-8f;
+        // wide codebooks: the matrix-pipe filter + exact evaluation of the survivors (vq_filter.hip); it leaves flag_count[1] != 0
+        // (and does nothing) when the codebook is outside the f16 range of its coefficients -- then, and only then, tier 1 runs
+        const bool filt = !margin && vqae::vq_filter_supported(K, D);
+        if (filt) {
+            vqae::ProfScope fprof(vqae::PROF_VQ_TIER1, stream, 3.0 * (double)N * K * D);
+            const int frc = vqae::vq_filter_run(z, embed, N, K, D, thr, w.idx32, w.flag_count, w.flag_list, w.ftab, stream);
+            fprof.done();
+            if (frc) return frc;
+        }
         // one workgroup per CU (128 KB LDS tile); persistent over row groups
         const unsigned grid = (unsigned)std::min<int64_t>(vqae::ceil_div(N, VQ_ROWS_PER_BLOCK), 256);
-        vqae::ProfScope prof(vqae::PROF_VQ_TIER1, stream, 3.0 * (double)N * K * D);
+        vqae::ProfScope prof(filt ? vqae::PROF_NONE : vqae::PROF_VQ_TIER1, stream, 3.0 * (double)N * K * D);
         vq_tier1_kernel<<<grid, VQ_WAVES * 64, lds_bytes, stream>>>(z, w.eT, N, K, Kpad, D, thr, w.idx32, margin,
-                                                                  w.flag_count, w.flag_list);
+                                                                  w.flag_count, w.flag_list, filt ? w.flag_count + 1 : nullptr);
         prof.done();
         VQAE_LAUNCH_CHECK();
     }

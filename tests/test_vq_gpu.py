@@ -212,3 +212,40 @@ def test_vq_projected_fused_equals_unfused_in_the_handle(amd, oracle, monkeypatc
     assert abs(float(lf) - float(lp)) <= 1e-5 * float(lp)
     if bool((idf == idp).all()):
         assert float((of - op).abs().max()) <= 1e-4 * float(op.abs().max())
+
+
+@pytest.mark.parametrize("N,K,scale", [(4096, 1024, 1.0), (1000, 300, 1.0), (129, 1024, 40.0), (2048, 64, 1e-3), (1, 32, 1.0), (70, 1000, 7.0)])
+def test_vq_filter_path_matches_oracle(amd, oracle, N, K, scale):
+    """D = 256 without the margin output takes the matrix-pipe filter (csrc/vq_filter.hip: f16 GEMM scores -> survivors ->
+    exact fp32 evaluation -> tier 2 for near ties).  Index-exact against the oracle on: duplicate / near-tie rows (adversarial
+    cases), K not a multiple of the 128-code padding, ragged N, codebooks and rows 40x and 1/1000 the usual magnitude
+    (the operands are rescaled by 8 / max|e|), and rows far outside the f16 range of z^3 (they take every code)."""
+    D = 256
+    z, embed = oracle.make_vq_case(D, K, max(N, 128), seed=11, adversarial=K >= 32)
+    z = (z[:N] * scale).contiguous()
+    embed = (embed * scale).contiguous()
+    if N >= 64:
+        z[5] *= 1000.0                                   # |z| * 8 / max|e| >> 30: the row leaves the filter's range
+        z[17] = embed[K // 2] + 1e-4 * scale             # a row next to a code
+        z[33] = 0.0
+    q, idx, loss, margin = amd.ops.vq_forward(z.cuda(), embed.cuda(), 1.0, want_margin=False)
+    torch.cuda.synchronize()
+    assert margin is None
+    oidx, _, _ = oracle.vq_argmin_p4(z, embed)
+    bad = (idx.cpu() != oidx).nonzero().flatten().tolist()
+    assert not bad, (bad[:10], idx.cpu()[bad[:10]].tolist(), oidx[bad[:10]].tolist())
+    assert torch.equal(q.cpu(), z + (embed[oidx] - z))
+
+
+def test_vq_filter_path_golden_and_switch(amd, oracle, monkeypatch):
+    """The reference's golden indices (D = 256, K = 1024) through the filter path, and the same call with the filter switched
+    off (VQAE_NO_VQ_FILTER is read once per process, so the comparison is with the margin-producing call, which always takes
+    vq_tier1_kernel): identical indices, loss and q."""
+    g = load_golden("vq_D256_K1024")
+    z, embed = oracle.make_vq_case(256, 1024, int(g["N"]), seed=int(g["seed"]))
+    qf, idxf, lossf, _ = amd.ops.vq_forward(z.cuda(), embed.cuda(), 1.0, want_margin=False)
+    qt, idxt, losst, _ = amd.ops.vq_forward(z.cuda(), embed.cuda(), 1.0, want_margin=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(idxf.cpu().numpy(), g["idx"].astype(np.int64))
+    assert torch.equal(idxf, idxt) and torch.equal(qf, qt) and float(lossf) == float(losst)
+    assert idxf[:4].tolist() == [0, 1, 2, 3]            # exact duplicates resolve to the lowest index

@@ -36,6 +36,13 @@ int trunk16_round_pack(const float* src, void* dst, int64_t n, int dtype, hipStr
 bool trunk16_head_supported(int c, int64_t m, int dtype);
 int trunk16_head(const float* x, const void* w1f, float b1a, float b1b, float b2a, float b2b, void* t1, int64_t m, int c,
                  int dtype, bool out32, hipStream_t stream);
+bool stem16_supported(int c0, int h, int w, int dtype);
+size_t stem16_weight_bytes(int cin);
+int stem16_pack_weight(const float* w_dev, int n_out, int cin, int dtype, void* out_dev, hipStream_t stream);
+int istem16(const void* x, int x_kind, const float* mean255, const float* inv_std255, const void* wf, const float* bias, int B,
+            int H, int W, int c0, float* y, int dtype, hipStream_t stream);
+int ostem16(const float* x, const void* wf, const float* bias, int B, int H, int W, int c, float* y, int y_nchw, int dtype,
+            hipStream_t stream);
 bool same8_16_supported(int c, int h, int w, int dtype);
 int same8_16_block(const float* x, float* y, const float* w1_packed, const void* w2h, const void* w3h, int B, int H, int W,
                    const float* scalars8, int dtype, hipStream_t stream);
@@ -146,6 +153,8 @@ struct vqae_handle {
     int C = 0, D = 0, K = 0;
     std::vector<Block> enc, dec;
     float *stem_w = nullptr, *stem_b = nullptr, *ostem_w = nullptr, *ostem_b = nullptr;
+    void *stem_wh = nullptr, *ostem_wh = nullptr;   // 16-bit modes: the stems' weights as 16-bit MFMA fragments (stem16.hip)
+    bool fuse_stem16 = true;
     float *embed = nullptr;
     float *pin_w = nullptr, *pin_b = nullptr, *pout_w = nullptr, *pout_b = nullptr;
     float *pin_wt = nullptr, *pout_wr = nullptr;   // fused projected VQ (vq_proj.hip): proj_in transposed [C][8], proj_out [C][8], rounded
@@ -741,8 +750,10 @@ int check_geometry(const vqae_handle* h, int B, int in_h, int in_w) {
 int run_encoder_convs(vqae_handle* h, const void* x, int x_kind, int B, int in_h, int in_w, int* zh, int* zw,
                       hipStream_t st) {
     int rc;
-    if ((rc = vqae::conv3x3_direct(x, x_kind, kMean255, kInv255, h->stem_w, h->stem_b, B, in_h, in_w,
-                                   h->cfg.in_channels, h->cfg.stem, h->buf[0], 0, g_dt, st))) return rc;
+    if (h->stem_wh && vqae::stem16_supported(h->cfg.stem, in_h, in_w, g_dt)) {          // 16-bit modes: the stem on the MFMA (stem16.hip)
+        if ((rc = vqae::istem16(x, x_kind, kMean255, kInv255, h->stem_wh, h->stem_b, B, in_h, in_w, h->cfg.stem, h->buf[0], g_dt, st))) return rc;
+    } else if ((rc = vqae::conv3x3_direct(x, x_kind, kMean255, kInv255, h->stem_w, h->stem_b, B, in_h, in_w,
+                                          h->cfg.in_channels, h->cfg.stem, h->buf[0], 0, g_dt, st))) return rc;
     int H = in_h, W = in_w;
     h->t1_ready = false;
     for (size_t i = 0; i < h->enc.size(); ++i)
@@ -784,6 +795,8 @@ int run_decoder_convs(vqae_handle* h, int B, int qh, int qw, int layout, float* 
     h->t1_ready = false;
     for (size_t i = 0; i < h->dec.size(); ++i)
         if ((rc = run_block(h, h->dec[i], i + 1 < h->dec.size() ? &h->dec[i + 1] : nullptr, B, H, W, st))) return rc;
+    if (h->ostem_wh && vqae::stem16_supported(h->cfg.stem, H, W, g_dt))
+        return vqae::ostem16(h->buf[0], h->ostem_wh, h->ostem_b, B, H, W, h->cfg.stem, out, layout == VQAE_LAYOUT_NCHW ? 1 : 0, g_dt, st);
     return vqae::conv3x3_direct(h->buf[0], 0, nullptr, nullptr, h->ostem_w, h->ostem_b, B, H, W, h->cfg.stem,
                                 h->cfg.in_channels, out, layout == VQAE_LAYOUT_NCHW ? 1 : 0, g_dt, st);
 }
@@ -830,6 +843,7 @@ extern "C" int vqae_create(const vqae_config* cfg, const vqae_tensor* tensors, i
     h->fuse_down = !(getenv("VQAE_NO_DOWN_FUSION") && atoi(getenv("VQAE_NO_DOWN_FUSION")));
     h->fuse_down16 = !(getenv("VQAE_NO_DOWN16") && atoi(getenv("VQAE_NO_DOWN16")));
     h->fuse_up16 = !(getenv("VQAE_NO_UP16") && atoi(getenv("VQAE_NO_UP16")));
+    h->fuse_stem16 = !(getenv("VQAE_NO_STEM16") && atoi(getenv("VQAE_NO_STEM16")));
     h->fuse_vq = !(getenv("VQAE_NO_VQ_FUSION") && atoi(getenv("VQAE_NO_VQ_FUSION")));
     h->C = cfg->stem << cfg->n_down;
     h->D = cfg->projection_dim > 0 ? cfg->projection_dim : h->C;
@@ -849,6 +863,10 @@ extern "C" int vqae_create(const vqae_config* cfg, const vqae_tensor* tensors, i
     if (has_enc) {
         if ((rc = find(tm, "encoder.in_stem.weight", (int64_t)cfg->stem * 3 * 9, &p)) || (rc = upload(h, p, (int64_t)cfg->stem * 27, &h->stem_w))) return bail(rc);
         if ((rc = find(tm, "encoder.in_stem.bias", cfg->stem, &p)) || (rc = upload(h, p, cfg->stem, &h->stem_b))) return bail(rc);
+        if (cfg->compute_dtype != VQAE_DT_F32 && h->fuse_stem16 && cfg->in_channels == 3 && (cfg->stem == 8 || cfg->stem == 16 || cfg->stem == 32)) {
+            if ((rc = dev_alloc(h, vqae::stem16_weight_bytes(3), &h->stem_wh))) return bail(rc);
+            if ((rc = vqae::stem16_pack_weight(h->stem_w, cfg->stem, 3, cfg->compute_dtype, h->stem_wh, nullptr))) return bail(rc);
+        }
         // encoder blocks: DownBlock levels (conv_block.py:35-47) then pre_enc (model.py:173-176)
         c = cfg->stem;
         for (int lvl = 0; lvl < cfg->n_down; ++lvl) {
@@ -897,6 +915,10 @@ extern "C" int vqae_create(const vqae_config* cfg, const vqae_tensor* tensors, i
     if (has_dec) {
         if ((rc = find(tm, "decoder.out_stem.weight", (int64_t)3 * cfg->stem * 9, &p)) || (rc = upload(h, p, (int64_t)cfg->stem * 27, &h->ostem_w))) return bail(rc);
         if ((rc = find(tm, "decoder.out_stem.bias", 3, &p)) || (rc = upload(h, p, 3, &h->ostem_b))) return bail(rc);
+        if (cfg->compute_dtype != VQAE_DT_F32 && h->fuse_stem16 && cfg->in_channels == 3 && (cfg->stem == 8 || cfg->stem == 16 || cfg->stem == 32)) {
+            if ((rc = dev_alloc(h, vqae::stem16_weight_bytes(cfg->stem), &h->ostem_wh))) return bail(rc);
+            if ((rc = vqae::stem16_pack_weight(h->ostem_w, 3, cfg->stem, cfg->compute_dtype, h->ostem_wh, nullptr))) return bail(rc);
+        }
         // decoder blocks: post_enc then UpBlock levels (conv_block.py:72-88)
         c = cfg->stem << cfg->n_down;
         for (int i = 0; i < cfg->n_enc; ++i) {

@@ -521,10 +521,34 @@ int conv3x3_direct(const void* x, int x_kind, const float* mean255, const float*
 }
 }  // namespace vqae
 
+namespace vqae {
+bool stem16_supported(int c0, int h, int w, int dtype);
+size_t stem16_weight_bytes(int cin);
+int stem16_pack_weight(const float* w_dev, int n_out, int cin, int dtype, void* out_dev, hipStream_t stream);
+int istem16(const void* x, int x_kind, const float* mean255, const float* inv_std255, const void* wf, const float* bias, int B,
+            int H, int W, int c0, float* y, int dtype, hipStream_t stream);
+int ostem16(const float* x, const void* wf, const float* bias, int B, int H, int W, int c, float* y, int y_nchw, int dtype,
+            hipStream_t stream);
+}  // namespace vqae
+
 extern "C" int vqae_conv3x3_direct_f32(const float* x, const uint8_t* x_u8, const float* mean255, const float* inv_std255,
                                        const float* w, const float* bias, int B, int H, int W, int cin, int cout,
                                        float* y, int dtype, void* stream) {
     VQAE_REQUIRE(dtype >= VQAE_DT_F32 && dtype <= VQAE_DT_F16, VQAE_ERR_INVALID, "conv3x3_direct: dtype %d", dtype);
+    // 16-bit modes, stem shapes the MFMA kernels cover (stem16.hip): the same dispatch the model handle uses
+    static const bool no16 = getenv("VQAE_NO_STEM16") && atoi(getenv("VQAE_NO_STEM16"));
+    const int c0 = cin == 3 ? cout : (cout == 3 ? cin : 0);
+    if (!no16 && dtype != VQAE_DT_F32 && c0 && (cin == 3) != (cout == 3) && vqae::stem16_supported(c0, H, W, dtype) && (cin == 3 || x)) {
+        VQAE_REQUIRE((x || x_u8) && w && bias && y, VQAE_ERR_INVALID, "conv3x3_direct: null pointer");
+        static thread_local void* wbuf = nullptr;                       // fragment scratch: packed per call on the caller's stream
+        if (!wbuf) VQAE_HIP_CHECK(hipMalloc(&wbuf, vqae::stem16_weight_bytes(32)));
+        int rc = vqae::stem16_pack_weight(w, cout, cin, dtype, wbuf, (hipStream_t)stream);
+        if (rc) return rc;
+        if (cin == 3)
+            return vqae::istem16(x_u8 ? (const void*)x_u8 : (const void*)x, x_u8 ? 2 : 0, mean255, inv_std255, wbuf, bias, B, H, W, cout, y, dtype,
+                                 (hipStream_t)stream);
+        return vqae::ostem16(x, wbuf, bias, B, H, W, cin, y, 0, dtype, (hipStream_t)stream);
+    }
     if (x_u8)
         return vqae::conv3x3_direct(x_u8, 2, mean255, inv_std255, w, bias, B, H, W, cin, cout, y, 0, dtype, (hipStream_t)stream);
     return vqae::conv3x3_direct(x, 0, nullptr, nullptr, w, bias, B, H, W, cin, cout, y, 0, dtype, (hipStream_t)stream);

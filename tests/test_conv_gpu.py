@@ -179,3 +179,49 @@ def test_fused_same_block_unsupported_shapes(amd):
     with pytest.raises(NotImplementedError):
         amd.ops.fixup_same_block(torch.zeros(1, 8, 16, 16).cuda(), torch.zeros(8).cuda(), torch.zeros(8).cuda(),
                                  torch.zeros(8).cuda(), [0] * 8)
+
+
+@pytest.mark.parametrize("tag,dt", [("bf16", torch.bfloat16), ("f16", torch.float16)])
+@pytest.mark.parametrize("c0,H,W", [(8, 16, 128), (16, 8, 64), (32, 24, 192)])
+def test_stem16_mfma_stems_match_autocast_reference(amd, oracle, tag, dt, c0, H, W):
+    """The 16-bit-MFMA stems (csrc/stem16.hip; taken for 16-bit dtypes when H % 8 == 0 and W % 64 == 0) against torch's conv
+    under CPU autocast -- operands and bias rounded to the 16-bit type, fp32 accumulation, rounded result -- on identical
+    inputs: in-stem from fp32 NHWC and from uint8 + normalisation, out-stem to 3 channels.  Zero padding at every border
+    (the tiles touch all four).  Equal up to isolated 1-ulp(16) flips of the result (summation order)."""
+    ulp = 2.0 ** -8 if tag == "bf16" else 2.0 ** -11
+    g = torch.Generator().manual_seed(c0 + H)
+
+    def check(y, ref):
+        ref = ref.float()
+        err = (nchw(y.cpu()) - ref).abs()
+        scale = max(1.0, float(ref.abs().max()))
+        assert float(err.max()) <= 1.01 * ulp * scale, float(err.max()) / scale
+        assert float((err > 1e-6 * scale).float().mean()) <= 2e-3
+
+    # in-stem, fp32 NHWC input
+    x = torch.randn(3, 3, H, W, generator=g)
+    w = torch.randn(c0, 3, 3, 3, generator=g) / 27 ** 0.5
+    b = torch.randn(c0, generator=g)
+    with torch.autocast("cpu", dtype=dt):
+        ref = F.conv2d(x, w, b, padding=1)
+    check(amd.ops.conv3x3_direct(nhwc(x).cuda(), w.cuda(), b.cuda(), dtype=tag), ref)
+    # in-stem, uint8 input normalised on the device
+    u8 = oracle.make_patches_u8(2, max(H, W), 5)[:, :H, :W].copy()
+    xn = oracle.normalize_u8(u8)
+    mean = [m * 255 for m in oracle.MEAN]
+    inv = [1.0 / (s * 255) for s in oracle.STD]
+    with torch.autocast("cpu", dtype=dt):
+        ref = F.conv2d(xn, w, b, padding=1)
+    y = amd.ops.conv3x3_direct(None, w.cuda(), b.cuda(), x_u8=torch.from_numpy(u8).cuda(), mean255=mean, inv_std255=inv, dtype=tag)
+    ref = ref.float()
+    err = (nchw(y.cpu()) - ref).abs()
+    scale = max(1.0, float(ref.abs().max()))
+    assert float(err.max()) <= 2.01 * ulp * scale      # the normalisation's own fp32 rounding can move an operand by one ulp(16)
+    assert float((err > 1e-6 * scale).float().mean()) <= 2e-2
+    # out-stem
+    xo = torch.randn(2, c0, H, W, generator=g)
+    wo = torch.randn(3, c0, 3, 3, generator=g) / (9 * c0) ** 0.5
+    bo = torch.randn(3, generator=g)
+    with torch.autocast("cpu", dtype=dt):
+        ref = F.conv2d(xo, wo, bo, padding=1)
+    check(amd.ops.conv3x3_direct(nhwc(xo).cuda(), wo.cuda(), bo.cuda(), dtype=tag), ref)

@@ -69,7 +69,9 @@ template <int C, int W, int MT> struct T16Cfg {
     static constexpr int WM = C <= 32 ? (MT < 4 ? MT : 4) : 1;   // wave groups along the pixels: with one channel slice (C <= 32) every m-tile
     static constexpr int MTW = MT / WM;               //   gets its own wave (4x the waves, each 4x shorter); MTW = m-tiles per wave
     static constexpr int NT = NW * WM * 64;           // threads
-    static constexpr int TW = W < 128 ? W : 128;      // columns a workgroup spans (wider grids: W / TW column blocks per row)
+    // columns a workgroup spans (W / TW column blocks per row).  C = 64 / 128 on grids >= 64 wide: 4 x 32 tiles (a 6 x 34 halo is
+    // 1.6x the tile; single-row 1 x 128 tiles re-read 3x) -- with the whole-line epilogues below: -22 % at C = 64, W = 64
+    static constexpr int TW = (C >= 64 && C <= 128 && W >= 64) ? 32 : (W < 128 ? W : 128);
     static constexpr int CB = W / TW;
     static constexpr int SEG = TW / 32;               // 32-pixel segments per tile row
     static constexpr int R = MT / SEG;                // image rows per workgroup (MT m-tiles of 32 pixels)
@@ -78,9 +80,10 @@ template <int C, int W, int MT> struct T16Cfg {
     static constexpr int PS = 2 * C + 16;             // LDS bytes per pixel: odd 16-B slot stride -> conflict-free b128 reads
     static constexpr int KS = C / 16;                 // k-slices per tap
     static constexpr int IMG_BYTES = (R + 2) * LW * PS;
-    // C >= 256: the epilogues' global accesses go through a wave-private LDS transpose (32 pixels x this wave's 32 channels)
-    // so that every wave-wide access is 1 KiB of whole 128-byte lines instead of 64 row pieces of 16 bytes
-    static constexpr bool EPI = C >= 256;             // measured: C = 256 -2.5 %, C = 128 / 64 neutral (kept direct)
+    // C >= 64: the epilogues' global accesses go through a wave-private LDS transpose (32 pixels x this wave's 32 channels)
+    // so that every wave-wide access is 1 KiB of whole 128-byte lines instead of 64 row pieces of 16 bytes (the L1 spends
+    // 62 % of its cycles waiting on outstanding misses in these kernels, and three quarters of its accesses were such pieces)
+    static constexpr bool EPI = C >= 64;              // measured on one box: C = 128 123 -> 114 us, C = 64 245 -> 190 us, C = 256 -2.5 %
     static constexpr int EPI_RS = 144;                // scratch row stride (128 B of fp32 + one 16-B slot: conflict-free both ways)
     static constexpr int EPI_BYTES = EPI ? 32 * EPI_RS : 0;
     static constexpr int LDS_BYTES = IMG_BYTES + NW * WM * EPI_BYTES;
@@ -567,7 +570,7 @@ bool trunk16_supported(int c, int h, int w, int dtype) {
     if (off || (dtype != VQAE_DT_BF16 && dtype != VQAE_DT_F16)) return false;
     const bool cw = (c == 128 && w == 32) || (c == 256 && w == 32) || (c == 64 && w == 64) || (c == 128 && w == 64) ||
                     (c == 64 && w == 128) || (c == 32 && w == 128) || (c == 32 && w == 256) || (c == 16 && w == 128) || (c == 16 && w == 256);
-    const int tw = w < 128 ? w : 128;
+    const int tw = (c >= 64 && c <= 128 && w >= 64) ? 32 : (w < 128 ? w : 128);       // T16Cfg::TW
     return cw && h >= 1 && h % (128 / tw) == 0;
 }
 

@@ -11,8 +11,9 @@
 //
 // A 256-thread workgroup owns ROWS x 32 output pixels (ROWS = 4; 2 at C = 128):
 //   stage    the (ROWS / 2 + 4) x 20 low-resolution window (clamped indices) of x (+ b1c), then of t1, in LDS as fp32
-//   resize   separable, in the order of bicubic_up2_kernel / ATen (out = sum_i wy_i * (sum_j wx_j * v_ij), left to right,
-//            unfused): a thread owns one output column and 4 channels, interpolates the window rows horizontally once and
+//   resize   separable, in the order of bicubic_up2_kernel / ATen (out = sum_i wy_i * (sum_j wx_j * v_ij), left to right; the
+//            accumulation steps as fmas -- the resize is this kernel's vector-issue bound, and its result is rounded to the
+//            16-bit type right after: <= 1 fp32 ulp from the unfused form): a thread owns one output column and 4 channels, interpolates the window rows horizontally once and
 //            combines them for the ROWS output rows; results go to LDS as 16-bit (the conv input cast): S (skip), U (branch)
 //   convs    v_mfma_f32_32x32x16_{bf16,f16}, weights (fragment order, from L2) as the row operand: conv2 from U -> t2 (16-bit,
 //            over U) -> conv3 from t2 and skip_conv from S -> epilogue, fp32 store.
@@ -140,7 +141,10 @@ void up16_kernel(const Up16K p) {
                 const char* src = win + (wr * WCN + wcb) * PSW + q * 16;
                 h[wr] = *reinterpret_cast<const f32x4*>(src) * wx[0];
 #pragma unroll
-                for (int k = 1; k < 4; ++k) h[wr] = h[wr] + *reinterpret_cast<const f32x4*>(src + k * PSW) * wx[k];
+                for (int k = 1; k < 4; ++k) {
+                    const f32x4 wk = {wx[k], wx[k], wx[k], wx[k]};
+                    h[wr] = __builtin_elementwise_fma(*reinterpret_cast<const f32x4*>(src + k * PSW), wk, h[wr]);
+                }
             }
 #pragma unroll
             for (int r = 0; r < ROWS; ++r) {
@@ -148,7 +152,10 @@ void up16_kernel(const Up16K p) {
                 const float* wy = (r & 1) ? w25 : w75;
                 f32x4 o = h[wrb] * wy[0];
 #pragma unroll
-                for (int k = 1; k < 4; ++k) o = o + h[wrb + k] * wy[k];
+                for (int k = 1; k < 4; ++k) {
+                    const f32x4 wk = {wy[k], wy[k], wy[k], wy[k]};
+                    o = __builtin_elementwise_fma(h[wrb + k], wk, o);
+                }
                 *reinterpret_cast<x4*>(dst + (r * 32 + c) * PS + q * 8) = __builtin_convertvector(o, x4);   // conv input cast
             }
         }

@@ -94,9 +94,13 @@ __device__ __forceinline__ float elu_act(float v) {
     const float e = __builtin_fmaf(sc, em, sc - 1.0f);
     return v > 0.f ? v : e;
 #else
-    // ELU(v) = median(v, e^v - 1, 0): for v >= 0, 0 <= v <= e^v - 1; for v < 0, v < e^v - 1 < 0 (e^v >= 1 + v).  Four
-    // instructions (v_mul, v_exp, v_add, v_med3) -- one fewer than max(v, 0) - clamp01(1 - e), same value bit for bit (e - 1 and
-    // -(1 - e) round alike).  The activation arithmetic is what bounds the small-channel 16-bit block kernels (PMC: vector issue).
+    // ELU(v) = median(v, e^v - 1, 0): in exact arithmetic 0 <= v <= e^v - 1 for v >= 0 and v < e^v - 1 < 0 for v < 0.  Four
+    // instructions (v_mul, v_exp, v_add, v_med3) instead of five for the select form.  In fp32 `e - 1` is a multiple of
+    // ulp(1) = 1.19e-7, so for 0 < v < ~3.5e-4 it can round BELOW v and the median returns it instead of v (e.g.
+    // ELU(1.0003e-4) -> 1.000166e-4, ELU(3e-8) -> 0): the positive branch is NOT the identity there, unlike torch's ELU.
+    // Bound: |elu_act(v) - ELU(v)| <= 1.2e-7 absolute on both branches (the same bound the negative branch has anyway;
+    // recorded in DESIGN.md section 4).  The activation arithmetic is what bounds the small-channel 16-bit block kernels
+    // (PMC: vector issue), hence the shorter form.
     const float e = __builtin_amdgcn_exp2f(v * 1.44269504088896341f);
     return __builtin_amdgcn_fmed3f(v, e - 1.0f, 0.0f);
 #endif

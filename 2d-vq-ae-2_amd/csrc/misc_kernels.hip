@@ -540,14 +540,18 @@ extern "C" int vqae_conv3x3_direct_f32(const float* x, const uint8_t* x_u8, cons
     const int c0 = cin == 3 ? cout : (cout == 3 ? cin : 0);
     if (!no16 && dtype != VQAE_DT_F32 && c0 && (cin == 3) != (cout == 3) && vqae::stem16_supported(c0, H, W, dtype) && (cin == 3 || x)) {
         VQAE_REQUIRE((x || x_u8) && w && bias && y, VQAE_ERR_INVALID, "conv3x3_direct: null pointer");
-        static thread_local void* wbuf = nullptr;                       // fragment scratch: packed per call on the caller's stream
-        if (!wbuf) VQAE_HIP_CHECK(hipMalloc(&wbuf, vqae::stem16_weight_bytes(32)));
+        // fragment scratch: stream-ordered allocation per call (any device, any number of streams per thread; the free is
+        // ordered after the kernel that reads it)
+        void* wbuf = nullptr;
+        VQAE_HIP_CHECK(hipMallocAsync(&wbuf, vqae::stem16_weight_bytes(32), (hipStream_t)stream));
         int rc = vqae::stem16_pack_weight(w, cout, cin, dtype, wbuf, (hipStream_t)stream);
-        if (rc) return rc;
-        if (cin == 3)
-            return vqae::istem16(x_u8 ? (const void*)x_u8 : (const void*)x, x_u8 ? 2 : 0, mean255, inv_std255, wbuf, bias, B, H, W, cout, y, dtype,
-                                 (hipStream_t)stream);
-        return vqae::ostem16(x, wbuf, bias, B, H, W, cin, y, 0, dtype, (hipStream_t)stream);
+        if (rc == VQAE_OK)
+            rc = cin == 3 ? vqae::istem16(x_u8 ? (const void*)x_u8 : (const void*)x, x_u8 ? 2 : 0, mean255, inv_std255, wbuf, bias, B, H, W,
+                                          cout, y, dtype, (hipStream_t)stream)
+                          : vqae::ostem16(x, wbuf, bias, B, H, W, cin, y, 0, dtype, (hipStream_t)stream);
+        const hipError_t fe = hipFreeAsync(wbuf, (hipStream_t)stream);
+        if (rc == VQAE_OK && fe != hipSuccess) return vqae::fail(VQAE_ERR_HIP, "conv3x3_direct: hipFreeAsync: %s", hipGetErrorString(fe));
+        return rc;
     }
     if (x_u8)
         return vqae::conv3x3_direct(x_u8, 2, mean255, inv_std255, w, bias, B, H, W, cin, cout, y, 0, dtype, (hipStream_t)stream);

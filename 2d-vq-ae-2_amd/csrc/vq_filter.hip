@@ -253,7 +253,8 @@ void vqf_main_kernel(const VqfK p) {
                     limS[r] = __builtin_fminf(__builtin_fminf(minw[r], minw[RT + r]), __builtin_fminf(minw[2 * RT + r], minw[3 * RT + r])) + 2.f * epsS[r];
                 lds_barrier();
 #pragma unroll
-                for (int mt = 0; mt < MTN; ++mt) lim[mt] = limS[mt * 32 + li];
+                for (int mt = 0; mt < MTN; ++mt)      // rows past N (staged as copies of row N - 1) keep no survivor: nothing of
+                    lim[mt] = row0 + mt * 32 + li < p.N ? limS[mt * 32 + li] : -INFINITY;   // theirs is ever addressed beyond z[N][D]
             }
         }
         lds_barrier();

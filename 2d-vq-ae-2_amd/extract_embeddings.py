@@ -127,6 +127,10 @@ def _num_codes(model) -> Optional[int]:
     return int(spec.num_embeddings) if spec is not None else None
 
 
+def _has_geometry(dataset) -> bool:
+    return all(hasattr(dataset, a) for a in ("_cum_lengths", "_sizes", "image_paths", "mask_paths"))
+
+
 def batch_meta(dataset, lo: int, hi: int):
     """(img_index [n] int64, patch_index [n, 2] int64, image paths, mask paths) of items [lo, hi) WITHOUT reading a
     pixel: the index -> (slide, row, col) rule of CAMELYON16SlicePatchDataSet.__getitem__ (camelyon16.py:184-190:
@@ -146,22 +150,146 @@ def batch_meta(dataset, lo: int, hi: int):
 class ShardBatchSampler(Sampler):
     """Batch sampler of one rank: of every global batch [k * bs, (k + 1) * bs) it yields only this rank's contiguous
     share (dist.shard_range), so a rank's loader workers read only the tiles that rank encodes -- host loading is
-    divided over the ranks, not replicated.  Every rank walks the same number of batches (a share may be empty)."""
+    divided over the ranks, not replicated.  Every rank walks the same number of batches (a share may be empty).
+    `tag_batches`: the share is prefixed with -(k + 1), the batch number the ring loader's workers pick their slot by."""
 
-    def __init__(self, n, batch_size, rank, world_size):
-        self.n, self.bs, self.rank, self.ws = int(n), int(batch_size), rank, world_size
+    def __init__(self, n, batch_size, rank, world_size, tag_batches=False):
+        self.n, self.bs, self.rank, self.ws, self.tag = int(n), int(batch_size), rank, world_size, tag_batches
+        self.skip = 0                                    # batches to leave out at the front (ring loader: its probe batch)
 
     def __len__(self):
-        return -(-self.n // self.bs)
+        return -(-self.n // self.bs) - self.skip
 
     def __iter__(self):
-        for b0 in range(0, self.n, self.bs):
+        for k, b0 in enumerate(range(0, self.n, self.bs)):
+            if k < self.skip:
+                continue
             lo, hi = vdist.shard_range(min(self.bs, self.n - b0), self.rank, self.ws)
-            yield list(range(b0 + lo, b0 + hi))
+            share = list(range(b0 + lo, b0 + hi))
+            yield ([-(k + 1)] + share) if self.tag else share
 
 
 def _collate(batch):
     return default_collate(batch) if batch else None
+
+
+class StageTimer:
+    """Stage breakdown of the whole-slide pipeline (tools/bench_slide.py): `host(name)` accumulates wall time of a
+    host-side stage, `gpu(name)` brackets device work with events on the current stream (resolved once, in `summary`,
+    so timing adds no synchronisation to the loop)."""
+
+    def __init__(self, device=None):
+        self.wall, self.events, self.device = {}, [], device
+        self.cuda = torch.cuda.is_available() and (device is None or torch.device(device).type == "cuda")
+
+    @contextlib.contextmanager
+    def host(self, name):
+        import time
+        t0 = time.perf_counter()
+        try:
+            yield
+        finally:
+            self.wall[name] = self.wall.get(name, 0.0) + time.perf_counter() - t0
+
+    @contextlib.contextmanager
+    def gpu(self, name):
+        if not self.cuda:
+            with self.host(name):
+                yield
+            return
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        try:
+            yield
+        finally:
+            b.record()
+            self.events.append((name, a, b))
+
+    def summary(self):
+        out = {"host_s": {k: round(v, 4) for k, v in self.wall.items()}, "gpu_s": {}}
+        if self.events:
+            torch.cuda.synchronize()
+            for name, a, b in self.events:
+                out["gpu_s"][name] = out["gpu_s"].get(name, 0.0) + a.elapsed_time(b) * 1e-3
+            out["gpu_s"] = {k: round(v, 4) for k, v in out["gpu_s"].items()}
+        return out
+
+
+@contextlib.contextmanager
+def _stage(timer, kind, name):
+    if timer is None:
+        yield
+    else:
+        with (timer.gpu(name) if kind == "gpu" else timer.host(name)):
+            yield
+
+
+class PinnedRing:
+    """Zero-copy host path of the ring loader: R batch slots in ONE anonymous shared mapping that the loader's worker
+    processes inherit over fork and that is page-locked for the GPU's DMA engines (hipHostRegister).  A worker collates
+    its tiles straight into slot k % R -- the only host-side copy of a pixel -- and sends back a few bytes; the consumer
+    issues the asynchronous H2D copy from the slot itself.  The stock DataLoader path moves every batch three times
+    (collate into shared memory, pin-memory thread, H2D) and its single pin thread tops out near 8 GB/s: a
+    16 k patches/s encoder eats 17 GB/s of 512 x 512 x 3 uint8 tiles + labels.
+    Slot reuse: with at most `in_flight` batches dispatched ahead of the consumer, slot k % R is rewritten only after
+    the consumer has fetched batch k + R - in_flight >= k + 2; the consumer waits for batch k's copy event before it
+    fetches batch k + 2 (run_eval), so R = in_flight + 2 slots suffice."""
+
+    def __init__(self, n_slots, n_max, img_shape, img_dtype, lab_shape, lab_dtype, pin=True):
+        import mmap
+        self.n_slots, self.n_max = int(n_slots), int(n_max)
+        self.img_shape, self.img_dtype = tuple(img_shape), img_dtype
+        self.lab_shape, self.lab_dtype = tuple(lab_shape), lab_dtype
+        self.img_bytes = int(np.prod(img_shape)) * torch.empty((), dtype=img_dtype).element_size()
+        self.lab_bytes = int(np.prod(lab_shape)) * torch.empty((), dtype=lab_dtype).element_size()
+        self.lab_off = -(-self.n_max * self.img_bytes // 4096) * 4096
+        self.slot_bytes = self.lab_off + -(-self.n_max * self.lab_bytes // 4096) * 4096
+        self.nbytes = self.slot_bytes * self.n_slots
+        self._mm = mmap.mmap(-1, self.nbytes)                     # MAP_SHARED | MAP_ANONYMOUS: shared with forked workers
+        self._buf = torch.frombuffer(self._mm, dtype=torch.uint8)
+        self.pinned = False
+        if pin and torch.cuda.is_available():
+            rc = torch.cuda.cudart().cudaHostRegister(self._buf.data_ptr(), self.nbytes, 0)
+            self.pinned = int(rc) == 0
+
+    def views(self, slot, n):
+        """(imgs [n, *img_shape], labels [n, *lab_shape]) views of slot `slot`."""
+        base = slot * self.slot_bytes
+        a = self._buf[base: base + n * self.img_bytes].view(self.img_dtype).reshape((n,) + self.img_shape)
+        b = self._buf[base + self.lab_off: base + self.lab_off + n * self.lab_bytes].view(self.lab_dtype).reshape((n,) + self.lab_shape)
+        return a, b
+
+    def close(self):
+        if self.pinned:
+            torch.cuda.cudart().cudaHostUnregister(self._buf.data_ptr())
+            self.pinned = False
+        self._buf = None
+        try:
+            self._mm.close()
+        except BufferError:                                        # a view is still alive somewhere: the mapping goes with it
+            pass
+
+
+class _RingItems(Dataset):
+    """What the ring loader's workers run: the tiles of one (tagged) batch share -> the ring slot of that batch."""
+
+    def __init__(self, dataset, ring, send_meta):
+        self.dataset, self.ring, self.send_meta = dataset, ring, send_meta
+
+    def __len__(self):
+        return len(self.dataset)
+
+    def __getitems__(self, keys):
+        k, idxs = -int(keys[0]) - 1, keys[1:]
+        imgs, labs = self.ring.views(k % self.ring.n_slots, len(idxs))
+        metas = []
+        for j, i in enumerate(idxs):
+            img, lab, meta = self.dataset[i]
+            imgs[j].copy_(torch.as_tensor(img))
+            labs[j].copy_(torch.as_tensor(lab))
+            if self.send_meta:
+                metas.append(meta)
+        return [(k, len(idxs), default_collate(metas) if metas else None)]
 
 
 def _pool_labels(lab, out_hw):
@@ -169,133 +297,260 @@ def _pool_labels(lab, out_hw):
     return ops.label_maxpool(lab.reshape(lab.shape[0], lab.shape[-2], lab.shape[-1]).to(torch.uint8), out_hw)
 
 
+_COMPACT = {1: torch.uint8, 2: getattr(torch, "uint16", torch.int16), 4: torch.int32}
+
+
 @torch.no_grad()
 def run_eval(model, dataset, batch_size=100, *, autocast_dtype=_REF_AUTOCAST, num_workers=6, prefetch_factor=5,
-             device=None, shard=True, encode_fn=None, pool_fn=None):
+             device=None, shard=True, encode_fn=None, pool_fn=None, loader="auto", timer=None, compact=False,
+             gather_to=None):
     """Batched encoder pass: drop-in for run_eval (extract_embeddings.py:92-138).  Yields, per batch, the reference's pair
         ((encoding_indices, names, img_index, patch_index), (labels_pooled, names, img_index, patch_index))
-    with tensors on `device`.  Defaults are the reference's: batch 100, 6 loader workers, prefetch 5, pinned memory
-    (:95-101), the encoder under fp16 autocast (:124-125; pass autocast_dtype=None for fp32 convolutions, or
+    with tensors on `device`.  Defaults are the reference's: batch 100, 6 loader workers, prefetch 5, page-locked host
+    buffers (:95-101), the encoder under fp16 autocast (:124-125; pass autocast_dtype=None for fp32 convolutions, or
     torch.bfloat16).
+
+    loader: "ring" -- workers collate into a shared page-locked ring and the H2D copy starts from there (PinnedRing;
+    needs num_workers > 0 and fixed-shape tensor items); "torch" -- the stock DataLoader with pin_memory, as the
+    reference builds it; "auto" -- "ring" when it applies.
+    compact=True returns the code tiles in the smallest unsigned dtype that holds the codebook (uint8 / uint16; what
+    get_encodings stitches and downloads) instead of the reference's int64.
 
     Under torch.distributed (one process per GPU) every global batch is sharded contiguously over the ranks: a
     rank's loader reads and its GPU encodes only its share (ShardBatchSampler); the shares are re-assembled with ONE
     fixed-size all-gather per batch (dist.all_gather_shares: uint8 / uint16 code tiles + pooled label tiles in one
     buffer, no size exchange, no host sync), issued asynchronously so it overlaps the next batch's encoder pass.
-    Every rank yields the full batch in the original order.
+    Every rank yields the full batch in the original order -- except that with gather_to=r the ranks other than r
+    yield None for the two data tensors (they take part in the collective but never unpack it: get_encodings' default).
 
     encode_fn(imgs_on_device) -> indices [b, h, w] and pool_fn(labels_on_device, out_hw) -> [b, out_hw, out_hw]
     replace the HIP encoder / max-pool (used by the CPU tests of the sharded path; the product default has no
     CPU fallback and raises without a GPU)."""
     device = torch.device(device) if device is not None else torch.device("cuda")
     rank, ws = vdist.world() if shard else (0, 1)
-    enc = encode_fn or (lambda x: _encode(model, x, autocast_dtype))
-    pool = pool_fn or _pool_labels
-    pin = device.type == "cuda"
-    extra = {"prefetch_factor": prefetch_factor} if num_workers else {}
-    if ws > 1:
-        loader = DataLoader(dataset, batch_sampler=ShardBatchSampler(len(dataset), batch_size, rank, ws),
-                            collate_fn=_collate, pin_memory=pin, num_workers=num_workers, **extra)
-    else:
-        loader = DataLoader(dataset, batch_size=batch_size, pin_memory=pin, num_workers=num_workers, **extra)
-    factor = _factor(model) if encode_fn is None else None
+    on_gpu = device.type == "cuda"
     n_codes = _num_codes(model) if model is not None else None
     code_bytes = 1 if (n_codes or 1 << 30) <= 256 else (2 if (n_codes or 1 << 30) <= 65536 else 4)
-    code_dtype = {1: torch.uint8, 2: torch.int16, 4: torch.int32}[code_bytes]
-    cap = vdist.gather_capacity(batch_size, ws)
+    code_dtype = _COMPACT[code_bytes]                              # what compact=True hands out (unsigned)
+    wire_dtype = {1: torch.uint8, 2: torch.int16, 4: torch.int32}[code_bytes]   # same bits; torch's cat / to() know these
+    native_compact = compact and encode_fn is None and hasattr(model, "with_dtype")
 
-    def finish(item):
-        """gathered buffer -> the reference's generator of two tuples, for one batch"""
-        (out, work, n, th, tw, meta, labels_dtype) = item
-        if work is not None:
-            work.wait()
-        idx_parts, pool_parts = [], []
-        nb = th * tw * code_bytes
-        for r in range(ws):
-            lo, hi = vdist.shard_range(n, r, ws)
-            rows = out[r, : hi - lo]
-            idx_parts.append(rows[:, :nb].contiguous().view(code_dtype).reshape(hi - lo, th, tw))
-            pool_parts.append(rows[:, nb:].reshape(hi - lo, th, tw))
-        idx = torch.cat(idx_parts, 0).to(torch.int64)
-        if code_bytes == 2:
-            idx = idx & 0xFFFF                                     # uint16 codes travelled as int16 bit patterns
-        pooled = torch.cat(pool_parts, 0).to(labels_dtype)
+    def default_enc(x):
+        if native_compact:                                         # NativeVQAE: codes leave the VQ kernel already compact
+            nat = model.with_dtype(autocast_dtype)
+            if x.dtype == torch.uint8:
+                return nat.encode_u8(x, idx_dtype=code_dtype)[1]
+            return nat.encode(x, "NCHW", idx_dtype=code_dtype, want_q=False, want_loss=False)[1]
+        return _encode(model, x, autocast_dtype)
+
+    enc = encode_fn or default_enc
+    pool = pool_fn or _pool_labels
+    geometry = _has_geometry(dataset)
+    n_items = len(dataset)
+    n_batches = -(-n_items // batch_size)
+    factor = _factor(model) if encode_fn is None else None
+    cap = vdist.gather_capacity(batch_size, ws)
+    want_data = gather_to is None or gather_to == rank
+
+    # ---- the loader ------------------------------------------------------------------------------------------------------
+    use_ring = loader == "ring" or (loader == "auto" and num_workers > 0 and n_items > 0)
+    ring, probe = None, None
+    if use_ring:
+        probe = dataset[0]
+        ok = isinstance(probe[0], torch.Tensor) and isinstance(probe[1], torch.Tensor)
+        if not ok and loader == "ring":
+            raise TypeError("run_eval(loader='ring'): dataset items must be (tensor, tensor, meta)")
+        use_ring = ok
+    sampler = ShardBatchSampler(n_items, batch_size, rank, ws, tag_batches=use_ring)
+    extra = {"prefetch_factor": prefetch_factor} if num_workers else {}
+    if use_ring:
+        in_flight = max(1, num_workers) * (prefetch_factor if num_workers else 1)
+        ring = PinnedRing(in_flight + 2, cap, probe[0].shape, probe[0].dtype, probe[1].shape, probe[1].dtype, pin=on_gpu)
+        if num_workers:
+            extra["multiprocessing_context"] = "fork"              # the workers must inherit the ring's mapping
+        dl = DataLoader(_RingItems(dataset, ring, send_meta=not geometry), batch_sampler=sampler,
+                        collate_fn=lambda b: b[0], pin_memory=False, num_workers=num_workers, **extra)
+    else:
+        dl = DataLoader(dataset, batch_sampler=sampler, collate_fn=_collate, pin_memory=on_gpu, num_workers=num_workers,
+                        **extra)
+    labels_dtype = getattr(dataset, "labels_dtype", None) or (probe[1].dtype if probe is not None else None)
+
+    def meta_of(k, n, collated):
+        """(img_index, patch_index, image paths, mask paths) of global batch k on every rank"""
+        b0 = k * batch_size
+        if geometry:
+            return batch_meta(dataset, b0, b0 + n)
+        if ws == 1:
+            return collated
+        # no geometry attributes (a Subset, a wrapper ...): the metadata travels with the tiles -- object gather (host sync)
+        import torch.distributed as tdist
+        parts = [None] * ws
+        tdist.all_gather_object(parts, collated)
+        parts = [p for p in parts if p is not None]
+        return (torch.cat([torch.as_tensor(p[0]) for p in parts]), torch.cat([torch.as_tensor(p[1]) for p in parts]),
+                sum((list(p[2]) for p in parts), []), sum((list(p[3]) for p in parts), []))
+
+    def emit(idx, pooled, meta):
         img_index, patch_index, img_path, label_path = meta
         return ((data, list(map(_extract_path, paths)), img_index, patch_index)
                 for data, paths in ((idx, img_path), (pooled, label_path)))
 
-    pending, grid_hw = None, None
-    for k, batch in enumerate(loader):
-        if ws == 1:
-            imgs, labels, (img_index, patch_index, img_path, label_path) = batch
-            x = imgs.to(device, non_blocking=True)
-            lab = labels.to(device, non_blocking=True)
-            idx = enc(x)
-            pooled = pool(lab, idx.shape[-1]).to(labels.dtype)
-            yield ((data, list(map(_extract_path, paths)), img_index, patch_index)
-                   for data, paths in ((idx, img_path), (pooled.reshape(idx.shape), label_path)))
-            continue
-        # ---- sharded: encode my share, pack, launch the gather, and only then hand out the PREVIOUS batch ----------
-        b0 = k * batch_size
-        n = min(batch_size, len(dataset) - b0)
-        meta = batch_meta(dataset, b0, b0 + n)
-        if batch is not None:
-            imgs, labels, _ = batch
-            x = imgs.to(device, non_blocking=True)
-            lab = labels.to(device, non_blocking=True)
-            idx = enc(x)
-            th, tw = int(idx.shape[-2]), int(idx.shape[-1])
-            pooled = pool(lab, tw).reshape(idx.shape[0], th * tw).to(torch.uint8)
-            codes = idx.to(code_dtype).reshape(idx.shape[0], th * tw).contiguous().view(torch.uint8)
-            mine = torch.zeros((cap, codes.shape[1] + pooled.shape[1]), dtype=torch.uint8, device=device)
-            mine[: idx.shape[0], : codes.shape[1]] = codes
-            mine[: idx.shape[0], codes.shape[1]:] = pooled
-            labels_dtype = labels.dtype
-            grid_hw = (th, tw, labels_dtype)
-        else:                                                      # empty share (a last batch shorter than the world size)
-            if grid_hw is None:                                    # ... before this rank ever encoded a tile
-                ps = getattr(dataset, "patch_size", None)
-                assert factor is not None and ps is not None, "run_eval: an empty share needs dataset.patch_size and a model factor"
-                grid_hw = (int(ps[0]) // factor, int(ps[1]) // factor, torch.uint8)
-            th, tw, labels_dtype = grid_hw
-            mine = torch.zeros((cap, th * tw * (code_bytes + 1)), dtype=torch.uint8, device=device)
-        out, work = vdist.all_gather_shares(mine, async_op=True)
+    def finish(item):
+        """gathered buffer -> the reference's generator of two tuples, for one batch"""
+        (out, work, n, th, tw, meta, ldt) = item
+        if work is not None:
+            work.wait()
+        if not want_data:
+            return emit(None, None, meta)
+        nb = th * tw * code_bytes
+        idx_parts, pool_parts = [], []
+        for r in range(ws):
+            lo, hi = vdist.shard_range(n, r, ws)
+            rows = out[r, : hi - lo]
+            idx_parts.append(rows[:, :nb].contiguous().view(wire_dtype).reshape(hi - lo, th, tw))
+            pool_parts.append(rows[:, nb:].reshape(hi - lo, th, tw))
+        idx, pooled = torch.cat(idx_parts, 0), torch.cat(pool_parts, 0)
+        if compact:
+            idx = idx.view(code_dtype)
+        else:
+            idx = idx.to(torch.int64)
+            if code_bytes == 2:
+                idx = idx & 0xFFFF                                 # uint16 codes travelled as int16 bit patterns
+        return emit(idx, pooled.to(ldt), meta)
+
+    pending, grid_hw, copied = None, None, []
+    it = iter(dl)
+    try:
+        for k in range(n_batches):
+            with _stage(timer, "host", "loader_wait"):
+                batch = next(it)
+            n = min(batch_size, n_items - k * batch_size)
+            imgs = labels = collated = None
+            if use_ring:
+                _, n_mine, collated = batch
+                if n_mine:
+                    imgs, labels = ring.views(k % ring.n_slots, n_mine)
+            elif batch is not None:
+                imgs, labels, collated = batch
+            if imgs is not None:
+                with _stage(timer, "gpu", "h2d"):
+                    x = imgs.to(device, non_blocking=True)
+                    lab = labels.to(device, non_blocking=True)
+                if use_ring and on_gpu:                            # slot k is free again once this copy has run
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    copied.append(ev)
+                    if len(copied) > 1:
+                        with _stage(timer, "host", "ring_backpressure"):
+                            copied.pop(0).synchronize()
+                with _stage(timer, "gpu", "encode"):
+                    idx = enc(x)
+                th, tw = int(idx.shape[-2]), int(idx.shape[-1])
+                if labels_dtype is None:
+                    labels_dtype = labels.dtype
+                with _stage(timer, "gpu", "label_pool"):
+                    pooled = pool(lab, tw)
+                grid_hw = (th, tw)
+            if ws == 1:                                            # the reference's single-GPU loop (:117-138)
+                if compact and idx.dtype == torch.int64:
+                    idx = idx.to(wire_dtype).view(code_dtype)
+                yield emit(idx, pooled.reshape(idx.shape).to(labels_dtype), meta_of(k, n, collated))
+                continue
+            # ---- sharded: pack my share, launch the gather, and only then hand out the PREVIOUS batch ---------------------
+            meta = meta_of(k, n, collated)
+            if imgs is not None:
+                with _stage(timer, "gpu", "pack"):
+                    nb = th * tw
+                    codes = (idx if idx.element_size() == code_bytes else idx.to(wire_dtype))
+                    codes = codes.reshape(idx.shape[0], nb).contiguous().view(torch.uint8)
+                    mine = torch.zeros((cap, codes.shape[1] + nb), dtype=torch.uint8, device=device)
+                    mine[: idx.shape[0], : codes.shape[1]] = codes
+                    mine[: idx.shape[0], codes.shape[1]:] = pooled.reshape(idx.shape[0], nb).to(torch.uint8)
+            else:                                                  # empty share (a last batch shorter than the world size)
+                if grid_hw is None:                                # ... before this rank ever encoded a tile
+                    ps = getattr(dataset, "patch_size", None)
+                    assert factor is not None and ps is not None, "run_eval: an empty share needs dataset.patch_size and a model factor"
+                    grid_hw = (int(ps[0]) // factor, int(ps[1]) // factor)
+                th, tw = grid_hw
+                mine = torch.zeros((cap, th * tw * (code_bytes + 1)), dtype=torch.uint8, device=device)
+            if labels_dtype is None:                               # no tile of mine yet: what every other rank sees in its batches
+                labels_dtype = dataset[0][1].dtype
+            with _stage(timer, "host", "gather_launch"):
+                out, work = vdist.all_gather_shares(mine, async_op=True)
+            if pending is not None:
+                yield finish(pending)
+            pending = (out, work, n, th, tw, meta, labels_dtype)
         if pending is not None:
             yield finish(pending)
-        pending = (out, work, n, th, tw, meta, labels_dtype)
-    if pending is not None:
-        yield finish(pending)
+    finally:
+        del it
+        if ring is not None:
+            if on_gpu:
+                torch.cuda.synchronize()
+            ring.close()
 
 
 def _stitch(sel, rc, grid):
     return ops.stitch_tiles(sel, rc, grid)
 
 
-def get_encodings(model, dataset, batch_size=100, stitch_fn=None, **kw) -> Iterator[Tuple[str, np.ndarray]]:
+def _runs(img_idx_np):
+    """[(lo, hi)] maximal runs of equal slide index in a batch (tiles arrive in dataset order: one run per slide)."""
+    if len(img_idx_np) == 0:
+        return []
+    cuts = np.flatnonzero(np.diff(img_idx_np)) + 1
+    edges = np.concatenate(([0], cuts, [len(img_idx_np)]))
+    return list(zip(edges[:-1].tolist(), edges[1:].tolist()))
+
+
+def get_encodings(model, dataset, batch_size=100, stitch_fn=None, replicate=False, timer=None,
+                  **kw) -> Iterator[Tuple[str, Optional[np.ndarray]]]:
     """Stitch code tiles into one `[32*rows, 32*cols]` grid per slide on the device and yield
     `(name, ndarray)` -- cast to the lowest dtype -- as soon as every tile of a slide has been seen
-    (extract_embeddings.py:43-89).  `stitch_fn(tiles, rc, grid)` replaces the HIP scatter (CPU tests only)."""
+    (extract_embeddings.py:43-89).  `stitch_fn(tiles, rc, grid)` replaces the HIP scatter (CPU tests only).
+
+    No host synchronisation per batch: the tiles of a slide are a contiguous run of the batch (a view, not a
+    boolean-mask gather), their (row, col) go up in one page-locked copy per batch, the slide grid lives on the device
+    in the codes' own width (uint8 for <= 256 codes: a 100 k-tile slide downloads 102 MB, not 819 MB of int64) and comes
+    down once, when the slide is complete.  Under torch.distributed only rank 0 stitches and downloads (it is the only
+    writer, save_encodings*); the other ranks drive the same collectives and yield `(name, None)`.  replicate=True
+    restores a full copy on every rank."""
     stitch = stitch_fn or _stitch
+    rank, ws = vdist.world() if kw.get("shard", True) else (0, 1)
+    active = replicate or ws == 1 or rank == 0
     arrays, counts = {}, {}
-    for ret_values in run_eval(model, dataset, batch_size=batch_size, **kw):
+    for ret_values in run_eval(model, dataset, batch_size=batch_size, compact=True, timer=timer,
+                               gather_to=None if (replicate or ws == 1) else 0, **kw):
         for (encodings, names, img_idx, patch_idx) in ret_values:
-            th, tw = int(encodings.shape[1]), int(encodings.shape[2])
-            names = np.asarray(names)
-            u_names, u_idx, u_counts = np.unique(names, return_counts=True, return_index=True)
             img_idx_np = np.asarray(img_idx)
-            for name, image_index, count in zip(u_names, img_idx_np[u_idx], u_counts):
+            rc_dev = None
+            for lo, hi in _runs(img_idx_np):
+                name, image_index = names[lo], int(img_idx_np[lo])
                 if name not in counts:
                     counts[name] = int(dataset._lengths[image_index])
-                    r, c = (int(v) for v in dataset._sizes[image_index])
-                    arrays[name] = torch.empty((r * th, c * tw), dtype=encodings.dtype, device=encodings.device)
-                mask = torch.as_tensor(img_idx_np == image_index)
-                sel = encodings[mask.to(encodings.device)]
-                rc = torch.as_tensor(np.asarray(patch_idx)[mask.numpy()], dtype=torch.int32, device=encodings.device)
-                stitch(sel, rc, arrays[name])                              # device scatter (:83-84)
-                counts[name] -= int(count)
+                    if active:
+                        th, tw = int(encodings.shape[1]), int(encodings.shape[2])
+                        r, c = (int(v) for v in dataset._sizes[image_index])
+                        arrays[name] = torch.empty((r * th, c * tw), dtype=encodings.dtype, device=encodings.device)
+                if active:
+                    with _stage(timer, "gpu", "stitch"):
+                        if rc_dev is None:                             # one upload per batch, page-locked when there is a GPU
+                            rc_host = torch.as_tensor(np.asarray(patch_idx), dtype=torch.int32)
+                            if encodings.is_cuda:
+                                rc_host = rc_host.pin_memory()
+                            rc_dev = rc_host.to(encodings.device, non_blocking=True)
+                        stitch(encodings[lo:hi], rc_dev[lo:hi], arrays[name])            # device scatter (:83-84)
+                counts[name] -= hi - lo
                 if counts[name] == 0:
                     counts.pop(name)
-                    yield str(name), cast_to_lowest_dtype(arrays.pop(name).cpu().numpy())
+                    if not active:
+                        yield str(name), None
+                        continue
+                    with _stage(timer, "host", "d2h"):
+                        host = arrays.pop(name).cpu().numpy()
+                    with _stage(timer, "host", "cast_lowest"):
+                        host = cast_to_lowest_dtype(host)
+                    yield str(name), host
 
 
 def save_encodings(root, model, dataset, **kw):
@@ -304,7 +559,7 @@ def save_encodings(root, model, dataset, **kw):
     rank, _ = vdist.world()
     written = []
     for name, array in get_encodings(model, dataset, **kw):
-        if rank == 0:
+        if rank == 0 and array is not None:
             out = Path(root) / "encodings" / (name + ".npy")
             out.parent.mkdir(parents=True, exist_ok=True)
             np.save(str(out), array)
@@ -319,11 +574,13 @@ def save_encodings_hdf5(out_path, model, dataset, **kw):
     Every finished slide is appended at once; under torch.distributed only rank 0 writes."""
     rank, _ = vdist.world()
     writer = hdf5.H5Writer(out_path) if rank == 0 else None
+    timer = kw.get("timer")
     try:
         for name, array in get_encodings(model, dataset, **kw):
-            if writer is not None:
+            if writer is not None and array is not None:
                 group, _, stem = name.rpartition("/")
-                writer.create_dataset(group or "images", stem, array)
+                with _stage(timer, "host", "hdf5_write"):
+                    writer.create_dataset(group or "images", stem, array)
     finally:
         if writer is not None:
             writer.close()

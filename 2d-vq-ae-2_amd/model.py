@@ -122,6 +122,15 @@ class _NativeMixin:
         self.refresh()
         return r
 
+    def __getstate__(self):
+        """copy.deepcopy / pickle: the device snapshot (a raw vqae_handle) and the back-reference to the parent VQAE are
+        per-object state -- a copy builds its own handle from its own parameters on first use, and a copied VQAE rebinds
+        its children to itself (VQAE.__setstate__)."""
+        d = self.__dict__.copy()
+        d.pop("_owner", None)
+        d["_native"] = None
+        return d
+
 
 class Encoder(_NativeMixin, nn.Module):
     _prefix = "encoder."
@@ -204,11 +213,18 @@ class VQAE(_NativeMixin, nn.Module):
         self.optim_conf, self.loss_f_conf = optim_conf, loss_f_conf
         self.encoder = Encoder(**_strip(encoder_conf))
         self.decoder = Decoder(**_strip(decoder_conf))
+        self._bind_children()
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+    def _bind_children(self):
         # the children run on the parent's handle (one device copy of the weights; it encodes and decodes)
         object.__setattr__(self.encoder, "_owner", weakref.ref(self))
         object.__setattr__(self.decoder, "_owner", weakref.ref(self))
-        for k, v in kwargs.items():
-            setattr(self, k, v)
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._bind_children()
 
     def _spec(self):
         return self.encoder._spec()

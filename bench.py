@@ -30,6 +30,14 @@ PEAK_HBM_GBS = 8000.0
 
 # BASELINE.json `configs` that a (--config, --dtype, --batch, --mode) combination reproduces on one GPU
 BASELINE_CONFIGS = {("B", "f32", 256, "full"): 1, ("A", "bf16", 256, "full"): 2, ("C", "f16", 256, "full"): 3}
+# short legs attached to the default (driver-run) line under "other_configs": (key, config, dtype, mode, prof class)
+OTHER_LEGS = [("configs[2]", "A", "bf16", "full", 1),                 # 512x512 deeper encoder, bf16, batch 256
+              ("configs[3]_per_gpu", "C", "f16", "full", 1),          # 1024-entry / 256-dim codebook, fp16, 256 per GPU
+              ("configs[4]_encode_only_f16", "A", "f16", "encode", 1),  # the whole-slide extractor's encoder pass (cfg A, fp16)
+              ("cfgB_bf16_full", "B", "bf16", "full", 1),
+              ("cfgB_f16_encode", "B", "f16", "encode", 1),
+              ("north_star_vq_argmin_D8", "A", "bf16", "full", 3),    # fused projected quantiser: HBM fraction
+              ("north_star_conv1x1", "B", "f32", "full", 2)]          # stand-alone 1x1 conv: fp32 MFMA fraction
 
 
 def host_cores():
@@ -112,44 +120,12 @@ def cpu_baseline(spec_name, size, params, embed, sample_batch, iters):
                        f"PyTorch-CPU oracle, {cores} threads"), x, out, taps["idx"]
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="B", choices=["A", "B", "C", "BM"])
-    ap.add_argument("--batch", type=int, default=256, help="patches per GPU per step")
-    ap.add_argument("--mode", default="full", choices=["full", "encode"])
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"],
-                    help="compute dtype of the convolutions (16-bit = torch.autocast semantics); headline: f32")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--prof-class", type=int, default=1, help="kernel class timed for `roofline` (1 = trunk 3x3 conv)")
-    args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # plain `python bench.py --gpus N`: start one fresh process per GPU through torch.distributed.run as children
-        # (nothing has touched the GPU in this process) and leave with their exit code
-        import subprocess
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"),
-               os.path.abspath(__file__)] + sys.argv[1:]
-        raise SystemExit(subprocess.call(cmd))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or "RANK" in os.environ          # under torchrun even a single rank goes through RCCL
-    if use_dist:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=dev)      # nccl == RCCL on ROCm
-
+def run_leg(args, ctx, headline):
+    """One measurement: W warm-up + K timed steps of (args.config, args.dtype, args.mode) at args.batch patches per GPU,
+    bracketed by barrier + synchronize; returns the result dict on rank 0 (None elsewhere)."""
     import vqae_amd
     from vqae_amd import _lib as L
+    world, rank, dev, use_dist, dist = ctx["world"], ctx["rank"], ctx["dev"], ctx["use_dist"], ctx["dist"]
     size = 512 if args.config == "A" else 256
     spec = vqae_amd.SPECS[args.config]
     params = synth_weights(args.config)
@@ -230,6 +206,7 @@ def main():
         torch.cuda.synchronize()
         h2d_value = B * n_h2d / (time.perf_counter() - t1)
 
+    res = None
     if rank == 0:
         total_patches = world * B * args.steps
         value = total_patches / dt
@@ -326,6 +303,77 @@ def main():
                 "idx_agreement": float((g_idx.cpu() == cidx).float().mean()),
                 "recon_mse_vs_cpu": float(((g_out.cpu() - cout) ** 2).mean()),
             }
+
+    del x, out, idx
+    nat.close()
+    return res if rank == 0 else None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="B", choices=["A", "B", "C", "BM"])
+    ap.add_argument("--batch", type=int, default=256, help="patches per GPU per step")
+    ap.add_argument("--mode", default="full", choices=["full", "encode"])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"],
+                    help="compute dtype of the convolutions (16-bit = torch.autocast semantics); headline: f32")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prof-class", type=int, default=1, help="kernel class timed for `roofline` (1 = trunk 3x3 conv)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short legs of the other BASELINE configs that the default N = 1 line carries")
+    ap.add_argument("--other-steps", type=int, default=5)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start one fresh process per GPU through torch.distributed.run as children
+        # (nothing has touched the GPU in this process) and leave with their exit code
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    use_dist = world > 1 or "RANK" in os.environ          # under torchrun even a single rank goes through RCCL
+    if use_dist:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev)      # nccl == RCCL on ROCm
+
+    import vqae_amd
+    from vqae_amd import _lib as L
+
+    ctx = dict(world=world, rank=rank, dev=dev, use_dist=use_dist, dist=dist if use_dist else None)
+    res = run_leg(args, ctx, headline=True)
+
+    # ---- the other BASELINE.json configs that fit one GPU, as short legs of the same (driver-timed) process -------
+    # `metric` / `value` / `config` stay the headline's; the legs land under "other_configs".  N = 1 and the default
+    # headline only; each leg frees its handle and workspace before the next one starts.
+    if rank == 0 and world == 1 and not args.no_other_configs and \
+            (args.config, args.dtype, args.batch, args.mode, args.prof_class) == ("B", "f32", 256, "full", 1):
+        other = {}
+        for key, cfgname, dt, mode, pclass in OTHER_LEGS:
+            leg = argparse.Namespace(**vars(args))
+            leg.config, leg.dtype, leg.mode, leg.prof_class = cfgname, dt, mode, pclass
+            leg.steps, leg.warmup, leg.no_cpu_baseline = args.other_steps, 2, True
+            log(f"other_configs leg {key}: cfg {cfgname} {dt} {mode}")
+            try:
+                r = run_leg(leg, ctx, headline=False)
+                other[key] = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config",
+                                                "roofline", "value_with_h2d") if k in r}
+            except Exception as e:          # a failed leg must not take the headline line with it
+                other[key] = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.empty_cache()
+        res["other_configs"] = other
+    if rank == 0:
         print(json.dumps(res), flush=True)
 
     if use_dist:

@@ -113,3 +113,26 @@ def test_mirrors_are_inference_only():
         m(x)
     with pytest.raises(NotImplementedError):
         m.encoder(x)
+
+
+def test_mirror_deepcopy_and_pickle_rebind_children(tmp_path):
+    """A copied / unpickled VQAE owns its children (its encoder / decoder resolve their handle through the COPY, not the
+    original) and carries no device snapshot; the original is untouched."""
+    import copy
+    import pickle
+    import torch
+    import vqae_amd
+    from vqae_amd.model import VQAE
+    m = VQAE.from_spec(vqae_amd.SPECS["tiny"])
+    c = copy.deepcopy(m)
+    assert c.encoder._owner() is c and c.decoder._owner() is c
+    assert m.encoder._owner() is m and m.decoder._owner() is m
+    assert c._native is None and c.encoder._native is None
+    with torch.no_grad():
+        c.encoder.in_stem.weight.add_(1.0)
+    assert not torch.equal(c.encoder.in_stem.weight, m.encoder.in_stem.weight)
+    r = pickle.loads(pickle.dumps(m))
+    assert r.encoder._owner() is r and r.decoder._owner() is r
+    for k, v in m.state_dict().items():
+        assert torch.equal(r.state_dict()[k], v), k
+    torch.save(m, tmp_path / "whole.pt")          # torch.save(model) pickles the module

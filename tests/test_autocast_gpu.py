@@ -51,6 +51,42 @@ def test_autocast_forward_matches_reference_fixture(amd, oracle, name, tag, size
     assert abs(float(loss) - float(g["loss"])) <= 5e-3 * float(g["loss"])
 
 
+@pytest.mark.parametrize("name,tag,size", [("A", "bf16", 512), ("C", "f16", 256), ("B", "bf16", 256)])
+def test_autocast_features_no_further_from_exact_than_the_reference(amd, oracle, name, tag, size):
+    """End-to-end pre-VQ features of the 68 / 74-block encoders at the fixture batch: HIP 16-bit, the reference's 16-bit
+    evaluation (the oracle under CPU autocast: bit-identical to the reference, tests/test_oracle_golden.py) and an fp64
+    evaluation with NO rounding points (fp32 weights widened) of the same input.  Criterion without a chosen fraction:
+    ||hip16 - exact|| <= 1.25 ||ref16 - exact|| (RMS over all features, and max) -- the HIP path is no further from the
+    true value than the reference's own 16-bit arithmetic is."""
+    from conftest import record_parity
+    g = load_golden(f"model_{name}_{tag}")
+    spec = oracle.SPECS[name]
+    p = params_for(oracle, name, g)
+    B = int(g["batch"])
+    x = oracle.make_patches(B, size, 0)
+    nat = amd.NativeVQAE(amd.SPECS[name], p, compute_dtype=tag)
+    z_hip = nat.encode_features(x.cuda()).permute(0, 3, 1, 2).cpu().double()
+    projected = spec.projection_dim > 0                 # the handle then reports the projected features (vq.py:190)
+    vq = "encoder.vq_layers.0."
+    with torch.autocast("cpu", dtype=TDT[tag]):
+        z_ref = oracle.encoder_features(x, p, spec)
+        if projected:
+            z_ref = torch.nn.functional.conv2d(z_ref, p[vq + "proj_in.weight"], p[vq + "proj_in.bias"])
+    z_ref = z_ref.double()
+    p64 = {k: v.double() for k, v in p.items() if torch.is_tensor(v) and v.is_floating_point()}
+    z_ex = oracle.encoder_features(x.double(), p64, spec)
+    if projected:
+        z_ex = torch.nn.functional.conv2d(z_ex, p64[vq + "proj_in.weight"], p64[vq + "proj_in.bias"])
+    assert z_hip.shape == z_ex.shape, (z_hip.shape, z_ex.shape)
+    eh, er = (z_hip - z_ex).abs(), (z_ref - z_ex).abs()
+    rh, rr = float((eh ** 2).mean().sqrt()), float((er ** 2).mean().sqrt())
+    mh, mr = float(eh.max()), float(er.max())
+    scale = float(z_ex.abs().max())
+    record_parity("features_vs_exact_fp64", model=name, dtype=tag, batch=B, rms_hip=rh / scale, rms_ref16=rr / scale,
+                  max_hip=mh / scale, max_ref16=mr / scale, rms_ratio=rh / rr, max_ratio=mh / mr)
+    assert rh <= 1.25 * rr and mh <= 1.25 * mr, (rh, rr, mh, mr)
+
+
 @pytest.mark.parametrize("tag", ["bf16", "f16"])
 def test_autocast_blocks_match_oracle(amd, oracle, tag):
     """Per-kernel check on identical inputs: one Fixup block (fused and unfused paths) vs the oracle under

@@ -126,15 +126,25 @@ def _cpu_stitch(tiles, rc, grid):
     return grid
 
 
-def _run_driver(ws_label):
+STITCH_CALLS = []
+
+
+def _counting_stitch(tiles, rc, grid):
+    STITCH_CALLS.append(int(tiles.shape[0]))
+    return _cpu_stitch(tiles, rc, grid)
+
+
+def _run_driver(ws_label, **kw):
     from vqae_amd.extract_embeddings import get_encodings
     g = load_golden("driver")
     tiles = torch.from_numpy(g["tiles"])
     ds = _FixtureSlides(g["sizes"])
     encode = lambda x: tiles[x.reshape(-1).long()]
     pool = lambda lab, out: torch.nn.functional.adaptive_max_pool2d(lab.float().reshape(lab.shape[0], 1, *lab.shape[-2:]), out)[:, 0].to(torch.uint8)
-    got = dict(get_encodings(None, ds, batch_size=7, stitch_fn=_cpu_stitch, device="cpu", num_workers=0,
-                             encode_fn=encode, pool_fn=pool))
+    del STITCH_CALLS[:]
+    kw.setdefault("num_workers", 0)
+    got = dict(get_encodings(None, ds, batch_size=7, stitch_fn=_counting_stitch, device="cpu",
+                             encode_fn=encode, pool_fn=pool, **kw))
     return g, ds, got
 
 
@@ -158,6 +168,64 @@ def test_run_eval_get_encodings_single_process(amd, oracle):
     assert sorted(ds.reads) == list(range(42))
 
 
+def test_ring_loader_equals_stock_loader(amd, oracle):
+    """loader='ring': worker processes collate straight into the shared ring (PinnedRing; page-locking needs a GPU and is
+    skipped here) -- same grids as the stock DataLoader path, with more batches than ring slots so that slots are reused."""
+    g, ds, got = _run_driver(1, loader="ring", num_workers=2, prefetch_factor=1)      # 6 batches through 4 slots
+    _check_driver(g, ds, got, oracle)
+    g, ds, got = _run_driver(1, loader="torch", num_workers=2, prefetch_factor=1)
+    _check_driver(g, ds, got, oracle)
+
+
+def test_run_eval_reference_contract_dtypes(amd):
+    """run_eval's own contract (not compact): int64 code tiles, labels in the dataset's label dtype, int64 index tensors,
+    '<parent>/<stem>' names (extract_embeddings.py:111-138) -- with both loaders."""
+    from vqae_amd.extract_embeddings import run_eval
+    g = load_golden("driver")
+    tiles = torch.from_numpy(g["tiles"])
+    pool = lambda lab, out: torch.nn.functional.adaptive_max_pool2d(lab.float().reshape(lab.shape[0], 1, *lab.shape[-2:]), out)[:, 0].to(torch.uint8)
+    for loader, nw in (("torch", 0), ("ring", 1)):
+        ds = _FixtureSlides(g["sizes"])
+        n = 0
+        for (idx, names, img_index, patch_index), (pooled, mnames, _, _) in run_eval(
+                None, ds, batch_size=7, device="cpu", num_workers=nw, loader=loader,
+                encode_fn=lambda x: tiles[x.reshape(-1).long()], pool_fn=pool):
+            assert idx.dtype == torch.int64 and pooled.dtype == torch.uint8 and pooled.shape == idx.shape
+            assert img_index.dtype == torch.int64 and tuple(patch_index.shape) == (idx.shape[0], 2)
+            assert torch.equal(idx, tiles[n:n + idx.shape[0]].long())
+            assert all(a.startswith("images/slide_") for a in names) and all(a.startswith("masks/slide_") for a in mnames)
+            n += idx.shape[0]
+        assert n == 42
+
+
+def test_run_eval_dataset_without_geometry_attributes(amd, oracle):
+    """A wrapper dataset without _cum_lengths / _sizes / paths: the metadata comes from the collated items instead
+    (ws = 1 here; under torch.distributed it travels by an object gather)."""
+    from vqae_amd.extract_embeddings import run_eval
+    g = load_golden("driver")
+    tiles = torch.from_numpy(g["tiles"])
+    inner = _FixtureSlides(g["sizes"])
+
+    class Wrapped(torch.utils.data.Dataset):
+        def __len__(self):
+            return len(inner)
+
+        def __getitem__(self, i):
+            return inner[i]
+
+    pool = lambda lab, out: torch.nn.functional.adaptive_max_pool2d(lab.float().reshape(lab.shape[0], 1, *lab.shape[-2:]), out)[:, 0].to(torch.uint8)
+    for loader, nw in (("torch", 0), ("ring", 1)):
+        seen = []
+        for (idx, names, img_index, patch_index), _ in run_eval(None, Wrapped(), batch_size=7, device="cpu", num_workers=nw,
+                                                                loader=loader, encode_fn=lambda x: tiles[x.reshape(-1).long()],
+                                                                pool_fn=pool):
+            seen += [(int(a), int(r), int(c)) for a, (r, c) in zip(img_index, patch_index.tolist())]
+        want = []
+        for s_, (r, c) in enumerate(g["sizes"]):
+            want += [(s_, i // int(c), i % int(c)) for i in range(int(r) * int(c))]
+        assert seen == want
+
+
 def _sharded_driver_worker(rank, ws, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -165,9 +233,23 @@ def _sharded_driver_worker(rank, ws, port, q):
     try:
         import vqae_amd  # noqa: F401
         from oracle import vqae_oracle
+        # default: rank 0 (the only writer) stitches and downloads; rank 1 drives the same collectives and gets (name, None)
         g, ds, got = _run_driver(ws)
+        names = ["images/slide_a", "images/slide_b", "masks/slide_a_mask", "masks/slide_b_mask"]
+        assert sorted(got) == sorted(names), sorted(got)
+        if rank == 0:
+            _check_driver(g, ds, got, vqae_oracle)
+            assert sum(STITCH_CALLS) == 2 * 42                      # every tile of both streams (codes, masks), once
+        else:
+            assert all(v is None for v in got.values()) and STITCH_CALLS == []      # no stitch, no D2H on rank 1
+        reads = sorted(ds.reads)
+        # replicate=True: a full copy on every rank
+        g, ds, got = _run_driver(ws, replicate=True)
         _check_driver(g, ds, got, vqae_oracle)
-        q.put((rank, True, sorted(ds.reads)))
+        # ... and through the ring loader (one worker process per rank)
+        g, ds, got = _run_driver(ws, replicate=True, loader="ring", num_workers=1, prefetch_factor=2)
+        _check_driver(g, ds, got, vqae_oracle)
+        q.put((rank, True, reads))
     except Exception as e:                                          # surface the failure in the parent
         import traceback
         q.put((rank, False, traceback.format_exc()))

@@ -48,7 +48,10 @@ def main():
     ap.add_argument("--cols", type=int, default=64)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--workers", type=int, default=8)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"])
+    ap.add_argument("--dtype", default="f16", choices=["f32", "bf16", "f16"])
+    ap.add_argument("--loader", default="auto", choices=["auto", "ring", "torch"])
+    ap.add_argument("--prefetch", type=int, default=3)
+    ap.add_argument("--out", default=None, help="also write the JSON record to this file")
     a = ap.parse_args()
     spec = vqae_amd.SPECS["A"]
     torch.manual_seed(0)
@@ -65,25 +68,54 @@ def main():
           (torch.tensor(vqae_amd.extract_embeddings.STD).cuda() * 255)).permute(0, 3, 1, 2).contiguous()
     nat.calibrate_codebook(xf, model.state_dict()["encoder.vq_layers.0.embed"])
     nat.reserve(a.batch, 512, 512)
-    out = os.path.join(tempfile.mkdtemp(prefix="vqae_slide_"), "slide.hdf5")
+    adt = None if a.dtype == "f32" else {"bf16": torch.bfloat16, "f16": torch.float16}[a.dtype]
+    from vqae_amd.extract_embeddings import StageTimer
+    # ---- the encoder alone on a resident uint8 batch (what the pipeline is measured against) ----------------------------
+    xb = torch.stack([ds[i][0] for i in range(a.batch)]).cuda()
+    enc = nat.with_dtype(adt)
+    for _ in range(3):
+        enc.encode_u8(xb, idx_dtype=torch.uint8)
     torch.cuda.synchronize()
     t0 = time.time()
-    save_encodings_hdf5(out, nat, ds, batch_size=a.batch, num_workers=a.workers)
+    reps = 10
+    for _ in range(reps):
+        enc.encode_u8(xb, idx_dtype=torch.uint8)
+    torch.cuda.synchronize()
+    enc_rate = a.batch * reps / (time.time() - t0)
+    del xb
+    # ---- the whole pipeline ------------------------------------------------------------------------------------------------
+    out = os.path.join(tempfile.mkdtemp(prefix="vqae_slide_"), "slide.hdf5")
+    timer = StageTimer()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    save_encodings_hdf5(out, nat, ds, batch_size=a.batch, num_workers=a.workers, prefetch_factor=a.prefetch,
+                        autocast_dtype=adt, loader=a.loader, timer=timer)
     torch.cuda.synchronize()
     dt = time.time() - t0
     n = len(ds)
     r = hdf5.H5Reader(out)
     grid, mask = r["images"]["slide_000"], r["masks"]["slide_000_mask"]
     assert grid.shape == (a.rows * 32, a.cols * 32) and mask.shape == grid.shape, (grid.shape, mask.shape)
-    # spot check: tile (r, c) of the file == a direct encode of that tile
-    for (rr, cc) in ((0, 0), (a.rows - 1, a.cols - 1), (a.rows // 2, 3)):
-        tile = ds[rr * a.cols + cc][0][None].cuda()
-        idx = nat.encode_u8(tile)[1][0].cpu().numpy()
+    # spot check: tile (r, c) of the file == a direct encode of that tile; its mask tile == the pooled label
+    for (rr, cc) in ((0, 0), (a.rows - 1, a.cols - 1), (a.rows // 2, 3), (a.rows // 3, a.cols // 2)):
+        item = ds[rr * a.cols + cc]
+        idx = enc.encode_u8(item[0][None].cuda())[1][0].cpu().numpy()
         assert np.array_equal(grid[rr * 32:(rr + 1) * 32, cc * 32:(cc + 1) * 32].astype(np.int64), idx), (rr, cc)
-    print(json.dumps({"workload": f"cfg A slide: {a.rows}x{a.cols} tiles of 512x512x3 uint8 -> [{grid.shape[0]},{grid.shape[1]}] "
-                                  f"{grid.dtype} code grid + mask -> HDF5, batch {a.batch}, {a.workers} loader workers, {a.dtype}",
-                      "patches": n, "seconds": round(dt, 3), "patches_per_s": round(n / dt, 1),
-                      "hdf5_bytes": os.path.getsize(out), "codes_used": int(np.unique(grid).size)}))
+        pooled = torch.nn.functional.adaptive_max_pool2d(item[1][None].float(), 32)[0, 0].numpy() > 0
+        assert np.array_equal(mask[rr * 32:(rr + 1) * 32, cc * 32:(cc + 1) * 32].astype(bool), pooled), (rr, cc)
+    rec = {"workload": f"cfg A slide: {a.rows}x{a.cols} tiles of 512x512x3 uint8 -> [{grid.shape[0]},{grid.shape[1]}] "
+                       f"{grid.dtype} code grid + {mask.dtype} mask -> HDF5, batch {a.batch}, {a.workers} loader workers "
+                       f"(prefetch {a.prefetch}, loader {a.loader}), {a.dtype}",
+           "patches": n, "seconds": round(dt, 3), "patches_per_s": round(n / dt, 1),
+           "encoder_only_patches_per_s": round(enc_rate, 1), "fraction_of_encoder_only": round(n / dt / enc_rate, 3),
+           "hdf5_bytes": os.path.getsize(out), "codes_used": int(np.unique(grid).size), "stages": timer.summary(),
+           "host_cores": len(os.sched_getaffinity(0))}
+    print(json.dumps(rec))
+    if a.out:
+        os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+        with open(a.out, "w") as f:
+            json.dump(rec, f, indent=1)
+    os.remove(out)
 
 
 if __name__ == "__main__":

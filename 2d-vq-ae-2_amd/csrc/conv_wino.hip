@@ -494,6 +494,104 @@ void fixup_conv1_kernel(const float* __restrict__ x, const float* __restrict__ w
         *reinterpret_cast<f32x4*>(yrow + (int64_t)(RP * i) * C) = *reinterpret_cast<const f32x4*>(trow + RP * i * LDT);
 }
 
+// Persistent form of fixup_conv1_kernel (round 3).  One launch = 2 workgroups per CU that loop over the 128-pixel tiles; the
+// NEXT tile's input rows are requested (16 x 16 B per thread, kept in registers) before this tile's MFMAs start and the
+// phase boundaries are LDS-only barriers (a __syncthreads() would drain those loads), so a workgroup's HBM reads run under
+// its own matrix work instead of only under its CU partner's: the one-shot form spends load + MFMA + store back to back
+// (33 k cycles per tile against 16.4 k of MFMA issue and 12.8 k of HBM time per tile and CU).
+template <int C>
+__global__ __launch_bounds__((WinoCfg<C>::NT), 2)
+void fixup_conv1p_kernel(const float* __restrict__ x, const float* __restrict__ w1f, float pa, float pb, float aa, float ab,
+                         float* __restrict__ y, const int n_tiles) {
+    using K = WinoCfg<C>;
+    constexpr int PX = K::PX, KS = K::KS, C4 = K::C4, RP = K::RP, LDT = K::LDT, WN = K::WN, MI = K::MI, NI = K::NI;
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // T[PX][LDT]
+    float* const T = lds;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, hh = lane >> 5;
+    const int cg = tid % C4, p0 = tid / C4;
+    const int wm = wave / WN, wn = wave % WN;
+    float* const trow = T + p0 * LDT + 4 * cg;
+    const float* const a0 = T + (wm * MI * 32 + li) * LDT + 4 * hh;
+    const float* const b0 = w1f + (wn * NI) * (KS * 256) + 4 * lane;
+    int tile = blockIdx.x;
+    f32x4 v[16];
+    if (tile < n_tiles) {
+        const float* const xrow = x + ((int64_t)tile * PX + p0) * C + 4 * cg;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xrow + (int64_t)(RP * i) * C));
+    }
+    for (; tile < n_tiles; tile += gridDim.x) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][e] = elu_act(v[i][e] + pa) + pb;
+            *reinterpret_cast<f32x4*>(trow + RP * i * LDT) = v[i];
+        }
+        vqae::lds_barrier();
+        const int nt = tile + gridDim.x;
+        if (nt < n_tiles) {                                            // next tile's rows: in flight under this tile's MFMAs
+            const float* const xrow = x + ((int64_t)nt * PX + p0) * C + 4 * cg;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xrow + (int64_t)(RP * i) * C));
+        }
+        f32x16 acc[MI][NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        {
+            f32x4 a[2][MI], bq[2][NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) a[0][mi] = *reinterpret_cast<const f32x4*>(a0 + mi * 32 * LDT);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) bq[0][ni] = *reinterpret_cast<const f32x4*>(b0 + ni * (KS * 256));
+#pragma unroll 1
+            for (int u2 = 0; u2 < KS; u2 += 2) {                       // a real loop (two k-slices per trip): bounds what hipcc hoists
+#pragma unroll
+                for (int uu = 0; uu < 2; ++uu) {
+                    const int u = u2 + uu;
+                    if (u + 1 < KS) {
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) a[(uu + 1) & 1][mi] = *reinterpret_cast<const f32x4*>(a0 + mi * 32 * LDT + 8 * (u + 1));
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) bq[(uu + 1) & 1][ni] = *reinterpret_cast<const f32x4*>(b0 + ni * (KS * 256) + 256 * (u + 1));
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                            for (int ni = 0; ni < NI; ++ni)
+                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[uu & 1][ni][r], a[uu & 1][mi][r], acc[mi][ni], 0, 0, 0);
+                }
+            }
+        }
+        vqae::lds_barrier();                                           // every wave is done reading T
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = elu_act(acc[mi][ni][4 * g + e] + aa) + ab;
+                    *reinterpret_cast<f32x4*>(T + (wm * MI * 32 + mi * 32 + li) * LDT + (wn * NI + ni) * 32 + 8 * g + 4 * hh) = o;
+                }
+        vqae::lds_barrier();
+        float* const yrow = y + ((int64_t)tile * PX + p0) * C + 4 * cg;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            *reinterpret_cast<f32x4*>(yrow + (int64_t)(RP * i) * C) = *reinterpret_cast<const f32x4*>(trow + RP * i * LDT);
+        vqae::lds_barrier();                                           // T is rewritten by the next tile's staging
+    }
+}
+
 // U[xi*4 + nu] = (G g G^T)[xi][nu] for g = w[n][k][3][3];  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
 __global__ void wino_weight_kernel(const float* __restrict__ w, int c, int dt, float* __restrict__ U) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;              // over n * c + k
@@ -590,8 +688,29 @@ static int launch_conv1(const float* x, const float* w1f, float pa, float pb, fl
         VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)fixup_conv1_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES));
         attr_set = true;
     }
+    static bool attr_p = false;
+    static int n_cu = 256;
+    if (!attr_p) {
+        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)fixup_conv1p_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES));
+        int dev = 0;
+        hipDeviceProp_t prop;
+        VQAE_HIP_CHECK(hipGetDevice(&dev));
+        VQAE_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        if (prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+        attr_p = true;
+    }
+    // read per call (a chain head: a handful of launches per forward pass) so that tests can switch forms inside one process
+    const char* e1 = getenv("VQAE_CONV1_ONESHOT");
+    const char* e2 = getenv("VQAE_CONV1_PERSIST_MIN_TILES");
+    const bool oneshot = e1 && atoi(e1);
+    const int64_t n_tiles = m / K::PX;
+    const int wgs = (int)std::min<int64_t>((K::LDS_BYTES * 2 <= 160 * 1024 ? 2 : 1) * n_cu, n_tiles);   // resident workgroups
+    const int64_t min_tiles = e2 ? atoll(e2) : 4ll * n_cu;          // below ~2 tiles per workgroup the loop has nothing to overlap
     ProfScope prof(C >= 128 ? PROF_CONV1X1_TRUNK : PROF_NONE, stream, 2.0 * (double)m * C * C);
-    fixup_conv1_kernel<C><<<(unsigned)(m / K::PX), K::NT, K::LDS_BYTES, stream>>>(x, w1f, pa, pb, aa, ab, y);
+    if (oneshot || C > 128 || n_tiles < min_tiles)
+        fixup_conv1_kernel<C><<<(unsigned)n_tiles, K::NT, K::LDS_BYTES, stream>>>(x, w1f, pa, pb, aa, ab, y);
+    else
+        fixup_conv1p_kernel<C><<<(unsigned)wgs, K::NT, K::LDS_BYTES, stream>>>(x, w1f, pa, pb, aa, ab, y, (int)n_tiles);
     prof.done();
     VQAE_LAUNCH_CHECK();
     return VQAE_OK;

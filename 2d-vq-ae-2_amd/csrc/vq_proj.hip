@@ -199,6 +199,184 @@ void vq_proj_fused_kernel(const VqProjK p) {
     }
 }
 
+// ---- round 3: 16 rows per wave step, projections on the fp32 MFMA, persistent waves ------------------------------------------
+// The row-per-lane kernel above runs at 30-34 % of HBM: its x loads / out stores are 16 B per lane at a C * 4-byte stride (64
+// line pieces per instruction), every wave of the chip is resident at once and walks load -> search -> store in lock-step
+// (HBM idles during the search), and the two projections are 2 x 8 C fp32 FMAs per row on the vector ALUs.  Here a wave
+// step is 16 rows, lane = (g = lane >> 4, r = lane & 15):
+//   proj_in   z^T[8 (of 16)][16 rows] = W_in[8 x C] . x^T[C x 16]  on v_mfma_f32_16x16x4_f32: lane (g, r) feeds x[row r][16 s +
+//             4 g + e] (one 16-byte load per s: 64 contiguous bytes per row and instruction) and ends up with z_{4g..4g+3}(row r)
+//   search    lane (g, r) scans the codes k = 4 i + g for row r with the tier-1 recipe (same instructions as above), the
+//             four partial (best, second, index) triples of a row are merged across g (lowest index on equal sums)
+//   proj_out  out^T[16 ch][16 rows] = W_out[16 x 8] . q^T[8 x 16] per 16-channel block, bias as the accumulator's start:
+//             lane (g, r) holds 4 consecutive channels of row r -> one 16-byte store, 64 contiguous bytes per row
+// and a wave loops over steps (persistent grid) with the NEXT step's x already requested (32 registers) while it searches,
+// so loads, search and stores of different waves -- and of one wave's consecutive steps -- overlap.
+template <int C, int DT, int WPS>
+__global__ __launch_bounds__(256, WPS)
+void vq_proj16_kernel(const VqProjK p, const int n_units) {
+    constexpr int NS = C / 16;                                                // 16-channel slices
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const s_emb = lds;                                                 // [Kpad4][8]
+    float* const s_win = s_emb + ((p.K + 3) & ~3) * PD;                       // [C][16 + 1]: W_in^T, j padded to 16 with zeros
+    float* const s_bout = s_win + C * 17;                                     // [C]
+    float* const s_bin = s_bout + C;                                          // [16] (8 real)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int kpad = (p.K + 3) & ~3;
+    for (int i = tid; i < kpad * PD / 4; i += 256)                            // pad codes: copies of the last one, masked in the search
+        reinterpret_cast<f32x4*>(s_emb)[i] = reinterpret_cast<const f32x4*>(p.embed)[i < p.K * PD / 4 ? i : (p.K - 1) * PD / 4 + (i & 1)];
+    for (int i = tid; i < C * 16; i += 256) s_win[(i >> 4) * 17 + (i & 15)] = (i & 15) < PD ? p.wt_in[(i >> 4) * PD + (i & 15)] : 0.f;
+    for (int i = tid; i < C; i += 256) s_bout[i] = p.b_out[i];
+    if (tid < 16) s_bin[tid] = tid < PD ? p.b_in[tid] : 0.f;
+    // proj_out's A operand: W_out[16 b + r][g], W_out[16 b + r][4 + g] -- kept in registers for the whole launch
+    float wo_lo[NS], wo_hi[NS];
+#pragma unroll
+    for (int b = 0; b < NS; ++b) {
+        wo_lo[b] = p.w_out[(16 * b + r) * PD + g];
+        wo_hi[b] = p.w_out[(16 * b + r) * PD + 4 + g];
+    }
+    __syncthreads();
+
+    const int stride = gridDim.x * 4;
+    int u = blockIdx.x * 4 + wave;
+    auto load_unit = [&](int unit, f32x4 (&xv)[NS]) {
+        int64_t row = (int64_t)unit * 16 + r;
+        row = row < p.N ? row : p.N - 1;                                      // tail rows recompute the last row, store nothing
+        const float* __restrict__ xr = p.x + row * C + 4 * g;
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) xv[s_] = *reinterpret_cast<const f32x4*>(xr + 16 * s_);
+    };
+    auto proj_in = [&](const f32x4 (&xv)[NS]) -> f32x4 {                      // -> z_{4g+i}(row r), i = 0..3 (lanes g < 2)
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+        const float* wa = s_win + (4 * g) * 17 + r;
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float w = wa[(16 * s_ + e) * 17];
+                const float xe = rnd16<DT>(xv[s_][e]);
+                if ((s_ & 1) == 0) a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, xe, a0, 0, 0, 0);
+                else a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, xe, a1, 0, 0, 0);
+            }
+        f32x4 zc;
+        const f32x4 bi = *reinterpret_cast<const f32x4*>(s_bin + 4 * g);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) zc[i] = rnd16<DT>((a0[i] + a1[i]) + bi[i]);
+        return zc;
+    };
+
+    f32x4 xv[NS];
+    f32x4 zc = {0.f, 0.f, 0.f, 0.f};
+    if (u < n_units) {
+        load_unit(u, xv);
+        zc = proj_in(xv);
+    }
+    for (; u < n_units; u += stride) {
+        const int un = u + stride;
+        if (un < n_units) load_unit(un, xv);                                  // in flight under this step's search
+        const int64_t row = (int64_t)u * 16 + r;
+        const bool live = row < p.N;
+        if (live && g < 2) *reinterpret_cast<f32x4*>(p.z + row * PD + 4 * g) = zc;
+        float z[PD];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { z[i] = __shfl(zc[i], r); z[4 + i] = __shfl(zc[i], 16 + r); }
+
+        // ---- tier-1 argmin over the codes k = 4 i + g, 4 codes in flight ---------------------------------------------------------
+        float b1 = INFINITY, b2 = INFINITY;
+        int i1 = 0;
+        const float* eb = s_emb + g * PD;
+#pragma unroll 1
+        for (int k0 = 0; k0 < kpad; k0 += 16) {
+            float s4[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x4 e0 = *reinterpret_cast<const f32x4*>(eb + (k0 + 4 * t) * PD);
+                const f32x4 e1 = *reinterpret_cast<const f32x4*>(eb + (k0 + 4 * t) * PD + 4);
+                float a = 0.f;
+#pragma unroll
+                for (int j = 0; j < PD; ++j) {
+                    float d = z[j] - (j < 4 ? e0[j] : e1[j - 4]);
+                    d = d * d;
+                    a = __builtin_fmaf(d, d, a);
+                }
+                s4[t] = a;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {                                     // k ascends: strict '<' keeps the lowest index
+                const int k = k0 + 4 * t + g;
+                const float sv = (k < p.K && k0 + 4 * t < kpad) ? s4[t] : INFINITY;   // pad codes / the ragged last group never win
+                const bool better = sv < b1;
+                b2 = fminf(b2, fmaxf(b1, sv));
+                i1 = better ? k : i1;
+                b1 = fminf(b1, sv);
+            }
+        }
+        // merge the four code subsets of a row (lanes r, 16 + r, 32 + r, 48 + r): smaller sum, lower index on equal sums
+#pragma unroll
+        for (int m = 16; m <= 32; m <<= 1) {
+            const float ob1 = __shfl_xor(b1, m), ob2 = __shfl_xor(b2, m);
+            const int oi1 = __shfl_xor(i1, m);
+            const bool take = ob1 < b1 || (ob1 == b1 && oi1 < i1);
+            b2 = fminf(fminf(b2, ob2), fmaxf(b1, ob1));
+            i1 = take ? oi1 : i1;
+            b1 = fminf(b1, ob1);
+        }
+        if (live && g == 0) {
+            p.idx32[row] = i1;
+            const float gap = b2 - b1;
+            if (p.margin) p.margin[row] = (b2 > 0.f) ? gap / b2 : 0.f;
+            if (!(gap > p.thr * b2)) {                                        // inside evaluation noise, exact tie, or NaN
+                const int slot = atomicAdd(p.flag_count, 1);
+                p.flag_list[slot] = (int)row;
+            }
+        }
+        // ---- q = z + (e[idx] - z) for j = g and 4 + g; out^T = W_out . q^T + b_out ----------------------------------------------------
+        const float zl = g == 0 ? z[0] : (g == 1 ? z[1] : (g == 2 ? z[2] : z[3]));
+        const float zh = g == 0 ? z[4] : (g == 1 ? z[5] : (g == 2 ? z[6] : z[7]));
+        const float el = s_emb[i1 * PD + g], eh = s_emb[i1 * PD + 4 + g];
+        const float ql = rnd16<DT>(zl + (el - zl)), qh = rnd16<DT>(zh + (eh - zh));
+        float* __restrict__ orow = p.out + row * C + 4 * g;
+#pragma unroll
+        for (int b = 0; b < NS; ++b) {
+            f32x4 acc = *reinterpret_cast<const f32x4*>(s_bout + 16 * b + 4 * g);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wo_lo[b], ql, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wo_hi[b], qh, acc, 0, 0, 0);
+            if (DT != VQAE_DT_F32) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = rnd16<DT>(acc[i]);
+            }
+            if (live) *reinterpret_cast<f32x4*>(orow + 16 * b) = acc;
+        }
+        if (un < n_units) zc = proj_in(xv);
+    }
+}
+
+template <int C, int DT>
+int launch_vq_proj16(const VqProjK& k, hipStream_t stream) {
+    const int n_units = (int)vqae::ceil_div(k.N, 16);
+    const size_t lds_bytes = ((size_t)((k.K + 3) & ~3) * PD + (size_t)C * 17 + C + 16) * sizeof(float);
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        VQAE_HIP_CHECK(hipGetDevice(&dev));
+        VQAE_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    // workgroups (of 4 waves) per CU = waves per SIMD the kernel is compiled for: 3 (168 registers, no spill) or 4 (128)
+    static const int wps = getenv("VQAE_VQ16_WPS") ? atoi(getenv("VQAE_VQ16_WPS")) : 3;
+    const unsigned grid = (unsigned)std::min<int64_t>(vqae::ceil_div(n_units, 4), (int64_t)n_cu * (wps == 4 ? 4 : 3));
+    vqae::ProfScope prof(vqae::PROF_VQ_TIER1, stream, (double)k.N * (29.0 * k.K + 4.0 * PD * k.C));
+    if (wps == 4) vq_proj16_kernel<C, DT, 4><<<grid, 256, lds_bytes, stream>>>(k, n_units);
+    else vq_proj16_kernel<C, DT, 3><<<grid, 256, lds_bytes, stream>>>(k, n_units);
+    prof.done();
+    VQAE_LAUNCH_CHECK();
+    return VQAE_OK;
+}
+
 // rows re-assigned by tier 2: recompute their output rows from the stored z and the corrected index
 template <int DT>
 __global__ __launch_bounds__(64)
@@ -269,7 +447,13 @@ extern "C" int vqae_vq_projected_f32(const float* x, const float* wt_in, const f
     k.margin = margin; k.N = N; k.C = C; k.K = K;
     k.thr = (4.0f * (float)PD + 16.0f) * 5.9604645e-8f;           // as vqae_vq_forward_f32
     VQAE_HIP_CHECK(hipMemsetAsync(k.flag_count, 0, 16, stream));
-    int rc = dtype == VQAE_DT_BF16 ? launch_vq_proj<VQAE_DT_BF16>(k, stream)
+    static const bool v1 = getenv("VQAE_VQ_PROJ_V1") && atoi(getenv("VQAE_VQ_PROJ_V1"));
+    int rc;
+    if (!v1 && C == 128 && K <= 1024)                                // the reference default (conf/model/vq_ae.yaml: 8 * 2^4 channels)
+        rc = dtype == VQAE_DT_BF16 ? launch_vq_proj16<128, VQAE_DT_BF16>(k, stream)
+           : dtype == VQAE_DT_F16 ? launch_vq_proj16<128, VQAE_DT_F16>(k, stream) : launch_vq_proj16<128, VQAE_DT_F32>(k, stream);
+    else
+        rc = dtype == VQAE_DT_BF16 ? launch_vq_proj<VQAE_DT_BF16>(k, stream)
            : dtype == VQAE_DT_F16 ? launch_vq_proj<VQAE_DT_F16>(k, stream) : launch_vq_proj<VQAE_DT_F32>(k, stream);
     if (rc) return rc;
     if ((rc = vqae::vq_tier2_run(k.z, embed, K, PD, k.idx32, k.flag_count, k.flag_list, stream))) return rc;

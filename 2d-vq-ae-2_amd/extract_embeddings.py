@@ -365,7 +365,8 @@ def run_eval(model, dataset, batch_size=100, *, autocast_dtype=_REF_AUTOCAST, nu
     extra = {"prefetch_factor": prefetch_factor} if num_workers else {}
     if use_ring:
         in_flight = max(1, num_workers) * (prefetch_factor if num_workers else 1)
-        ring = PinnedRing(in_flight + 2, cap, probe[0].shape, probe[0].dtype, probe[1].shape, probe[1].dtype, pin=on_gpu)
+        with _stage(timer, "host", "ring_setup"):
+            ring = PinnedRing(in_flight + 2, cap, probe[0].shape, probe[0].dtype, probe[1].shape, probe[1].dtype, pin=on_gpu)
         if num_workers:
             extra["multiprocessing_context"] = "fork"              # the workers must inherit the ring's mapping
         dl = DataLoader(_RingItems(dataset, ring, send_meta=not geometry), batch_sampler=sampler,
@@ -418,8 +419,11 @@ def run_eval(model, dataset, batch_size=100, *, autocast_dtype=_REF_AUTOCAST, nu
                 idx = idx & 0xFFFF                                 # uint16 codes travelled as int16 bit patterns
         return emit(idx, pooled.to(ldt), meta)
 
-    pending, grid_hw, copied = None, None, []
-    it = iter(dl)
+    pending, grid_hw, copied, encoded, depth = None, None, [], [], 3
+    if on_gpu:
+        main_stream, copy_stream = torch.cuda.current_stream(device), torch.cuda.Stream(device)
+    with _stage(timer, "host", "loader_start"):
+        it = iter(dl)
     try:
         for k in range(n_batches):
             with _stage(timer, "host", "loader_wait"):
@@ -433,16 +437,29 @@ def run_eval(model, dataset, batch_size=100, *, autocast_dtype=_REF_AUTOCAST, nu
             elif batch is not None:
                 imgs, labels, collated = batch
             if imgs is not None:
-                with _stage(timer, "gpu", "h2d"):
-                    x = imgs.to(device, non_blocking=True)
-                    lab = labels.to(device, non_blocking=True)
-                if use_ring and on_gpu:                            # slot k is free again once this copy has run
-                    ev = torch.cuda.Event()
-                    ev.record()
-                    copied.append(ev)
-                    if len(copied) > 1:
-                        with _stage(timer, "host", "ring_backpressure"):
-                            copied.pop(0).synchronize()
+                if on_gpu:
+                    # H2D on its own stream: batch k + 1 goes up while batch k is being encoded (PCIe moves 105 MB per batch of
+                    # 100 uint8 512 x 512 tiles + labels: 1.9 ms of the 7 ms the encoder needs).  The host may run at most
+                    # `depth` batches ahead of the encoder (device memory for the inputs stays bounded).
+                    if len(encoded) >= depth:
+                        with _stage(timer, "host", "encoder_backpressure"):
+                            encoded.pop(0).synchronize()
+                    with torch.cuda.stream(copy_stream):
+                        with _stage(timer, "gpu", "h2d"):
+                            x = imgs.to(device, non_blocking=True)
+                            lab = labels.to(device, non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(copy_stream)
+                    main_stream.wait_event(ev)
+                    x.record_stream(main_stream)
+                    lab.record_stream(main_stream)
+                    if use_ring:                                   # slot k is free again once this copy has run
+                        copied.append(ev)
+                        if len(copied) > 1:
+                            with _stage(timer, "host", "ring_backpressure"):
+                                copied.pop(0).synchronize()
+                else:
+                    x, lab = imgs.to(device), labels.to(device)
                 with _stage(timer, "gpu", "encode"):
                     idx = enc(x)
                 th, tw = int(idx.shape[-2]), int(idx.shape[-1])
@@ -450,6 +467,10 @@ def run_eval(model, dataset, batch_size=100, *, autocast_dtype=_REF_AUTOCAST, nu
                     labels_dtype = labels.dtype
                 with _stage(timer, "gpu", "label_pool"):
                     pooled = pool(lab, tw)
+                if on_gpu:
+                    ev = torch.cuda.Event()
+                    ev.record(main_stream)
+                    encoded.append(ev)
                 grid_hw = (th, tw)
             if ws == 1:                                            # the reference's single-GPU loop (:117-138)
                 if compact and idx.dtype == torch.int64:

@@ -333,3 +333,27 @@ def test_16bit_down_up_kernels_on_odd_batches_and_non_square_inputs(amd, oracle,
     n_blocks = 12
     assert float(e.max()) <= 4 * ULP[tag] * scale * np.sqrt(n_blocks) and float(e.mean()) <= 0.5 * ULP[tag] * scale
     assert float(ed.max()) <= 4 * ULP[tag] * dscale * np.sqrt(n_blocks) and float(ed.mean()) <= 0.5 * ULP[tag] * dscale
+
+
+@pytest.mark.parametrize("name", ["mid", "midC", "midW"])
+def test_persistent_conv1_equals_one_shot_bitwise(amd, oracle, name, monkeypatch):
+    """fixup_conv1p_kernel (persistent workgroups, next tile's rows prefetched under the MFMAs; taken from 4 tiles per CU
+    on) against the one-shot kernel on the fp32 chain heads of the mid models: same MFMA order -> bit-identical."""
+    spec, p, x, taps = oracle_taps(oracle, name, "f32")
+    nat = amd.NativeVQAE(amd.SPECS[name], p)
+    n = 0
+    for side, blocks, first_in in block_lists(oracle, spec):
+        ins = [taps[first_in]] + [taps[b[0]] for b in blocks[:-1]]
+        for i, (prefix, mode, ci, co) in enumerate(blocks):
+            if mode != "same" or ci not in (32, 64, 128):
+                continue
+            xin = nhwc(ins[i]).cuda()
+            monkeypatch.setenv("VQAE_CONV1_ONESHOT", "1")
+            a = nat.run_blocks(side, i, 1, xin)
+            monkeypatch.delenv("VQAE_CONV1_ONESHOT")
+            monkeypatch.setenv("VQAE_CONV1_PERSIST_MIN_TILES", "1")
+            b = nat.run_blocks(side, i, 1, xin)
+            monkeypatch.delenv("VQAE_CONV1_PERSIST_MIN_TILES")
+            assert torch.equal(a, b), (prefix, ci)
+            n += 1
+    assert n >= 2

@@ -141,10 +141,14 @@ def _sharded_gpu_worker(rank, ws, port, q):
         p["encoder.vq_layers.0.embed"] = torch.from_numpy(g["embed"])
         nat = vqae_amd.NativeVQAE(vqae_amd.SPECS["tiny"], p)
         ds = SyntheticSlideDataset([(3, 2), (2, 3)], patch_size=32, raw=True, names=["a", "b"])
-        sharded = dict(get_encodings(nat, ds, batch_size=5, num_workers=0))                 # ranks split every batch 3 + 2
         alone = dict(get_encodings(nat, ds, batch_size=5, num_workers=0, shard=False))      # this rank encodes everything
-        ok = set(sharded) == set(alone) and all(np.array_equal(sharded[k], alone[k]) and sharded[k].dtype == alone[k].dtype for k in alone)
-        q.put((rank, ok, ""))
+        same = lambda got: set(got) == set(alone) and all(np.array_equal(got[k], alone[k]) and got[k].dtype == alone[k].dtype for k in alone)
+        sharded = dict(get_encodings(nat, ds, batch_size=5, num_workers=0))                 # ranks split every batch 3 + 2
+        # default: only rank 0 (the writer) stitches and downloads; rank 1 drives the collectives and yields (name, None)
+        ok = same(sharded) if rank == 0 else (set(sharded) == set(alone) and all(v is None for v in sharded.values()))
+        ok = ok and same(dict(get_encodings(nat, ds, batch_size=5, num_workers=0, replicate=True)))
+        ok = ok and same(dict(get_encodings(nat, ds, batch_size=5, num_workers=2, prefetch_factor=2, loader="ring", replicate=True)))
+        q.put((rank, ok, "" if ok else f"rank {rank}: sharded grids differ from the single-process grids"))
     except Exception:
         import traceback
         q.put((rank, False, traceback.format_exc()))

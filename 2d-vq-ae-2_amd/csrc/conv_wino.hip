@@ -62,8 +62,13 @@ struct WinoK {
 constexpr int BPF = 6;                   // weight-fragment prefetch distance (k-slices)
 
 template <int C> struct WinoCfg {
+#ifdef VQAE_WINO_SMALL_WG                               // experiment: half-size workgroups (2 waves), 4 per CU, at C = 32 / 64
+    static constexpr int W = C >= 128 ? 32 : (C == 64 ? 32 : 64);
+    static constexpr int NT = C == 256 ? 512 : (C >= 128 ? 256 : 128);
+#else
     static constexpr int W = C >= 128 ? 32 : (C == 64 ? 64 : 128);   // columns a workgroup spans (the image may be k times wider)
     static constexpr int NT = C == 256 ? 512 : 256;    // threads: at C = 256 eight waves (one per 32-channel slice), one workgroup per CU
+#endif
     static constexpr int NW = NT / 64;
     static constexpr int PX = 4 * W;                   // output pixels per workgroup (4 image rows)
     static constexpr int TILES = PX / 4;               // 2x2 output tiles per workgroup
@@ -658,7 +663,7 @@ namespace vqae {
 // fp32: C in {256, 128, 64, 32} on a grid whose width is a multiple of the workgroup's column span (32, 64, 128); 16-bit autocast
 // modes: C = 32 only (the wider levels have a 16-bit MFMA kernel with fused tails, conv_mfma.hip)
 bool wino_trunk_supported(int c, int h, int w, int dtype) {
-    const int span = (c == 256 || c == 128) ? 32 : (c == 64 ? 64 : (c == 32 ? 128 : 0));
+    const int span = (c == 256 || c == 128) ? 32 : (c == 64 ? WinoCfg<64>::W : (c == 32 ? WinoCfg<32>::W : 0));
     if (span == 0 || (dtype != VQAE_DT_F32 && c != 32)) return false;
     return w >= span && w % span == 0 && h >= 4 && h % 4 == 0;
 }
@@ -675,7 +680,7 @@ int wino_transform_weight(const float* w_oihw_dev, int c, int dtype, float* U_de
 // chain-head conv1 (fixup_conv1_kernel): fp32, C in {128, 64, 32}, M a multiple of the kernel's pixel tile
 bool fixup_conv1_supported(int c, int64_t m) {
     if (c != 256 && c != 128 && c != 64 && c != 32) return false;
-    const int px = c >= 128 ? 128 : (c == 64 ? 256 : 512);
+    const int px = c >= 128 ? 128 : (c == 64 ? WinoCfg<64>::PX : WinoCfg<32>::PX);
     return m > 0 && m % px == 0;
 }
 

@@ -150,6 +150,48 @@ def test_vq_projected_index_exact_on_identical_z(amd, oracle):
     q = z + (embed[idx.cpu()] - z)
     want = torch.nn.functional.linear(q, w_out, b_out)
     assert float((out.cpu() - want).abs().max()) <= 2e-6 * float(want.abs().max())
+    # without the margin output the search runs behind the f16 matrix-pipe filter (vq_proj16_kernel): same indices, bit for bit
+    out2, idx2, loss2, zz2, _ = amd.ops.vq_projected(x.cuda(), w_in.cuda(), torch.zeros(8).cuda(), embed.cuda(), w_out.cuda(),
+                                                     b_out.cuda(), want_z=True)
+    torch.cuda.synchronize()
+    assert torch.equal(zz2.cpu(), z)
+    assert np.array_equal(idx2.cpu().numpy(), ref), f"filter path: {(idx2.cpu().numpy() != ref).sum()} index mismatches"
+    assert torch.equal(out2, out) and float(loss2) == float(loss)
+
+
+@pytest.mark.parametrize("N,K,scale", [(4096, 256, 1.0), (1000, 64, 1.0), (129, 256, 40.0), (2048, 256, 1e-3), (1, 32, 1.0), (70, 240, 7.0),
+                                       (4096, 250, 1.0), (512, 512, 1.0)])
+def test_vq_projected_filter_path_index_exact(amd, oracle, N, K, scale):
+    """C = 128 without the margin output takes vq_proj16_kernel's filter (one f16 MFMA per 16 rows x 16 codes -> survivors ->
+    exact tier-1 evaluation -> tier 2 for near ties; K > 256 or K % 16 != 0: every code exactly).  proj_in is a channel
+    selection, so z is known exactly and the indices must equal the oracle's on adversarial rows (duplicated codes, exact
+    hits, 0-4 ulp near ties), ragged N, 40x / 0.001x magnitudes and rows outside the f16 range of z^3."""
+    C = 128
+    z, embed = oracle.make_vq_case(8, K, max(N, 128), seed=5, adversarial=K >= 32)
+    z = (z[:N] * scale).contiguous()
+    embed = (embed * scale).contiguous()
+    if N >= 64:
+        z[5] *= 1000.0                                   # leaves the filter's range: the wave step scans every code
+        z[17] = embed[K // 2] + 1e-4 * scale
+        z[33] = 0.0
+    sel = [3, 17, 29, 45, 64, 90, 101, 127]
+    w_in = torch.zeros(8, C)
+    for j, c in enumerate(sel):
+        w_in[j, c] = 1.0
+    x = torch.zeros(N, C)
+    x[:, sel] = z
+    gen = torch.Generator().manual_seed(2)
+    w_out, b_out = torch.randn(C, 8, generator=gen), torch.randn(C, generator=gen)
+    out, idx, loss, zz, _ = amd.ops.vq_projected(x.cuda(), w_in.cuda(), torch.zeros(8).cuda(), embed.cuda(), w_out.cuda(), b_out.cuda(),
+                                                 want_z=True)
+    torch.cuda.synchronize()
+    assert torch.equal(zz.cpu(), z)
+    oidx, _, _ = oracle.vq_argmin_p4(z, embed)
+    bad = (idx.cpu() != oidx).nonzero().flatten().tolist()
+    assert not bad, (bad[:10], idx.cpu()[bad[:10]].tolist(), oidx[bad[:10]].tolist())
+    q = z + (embed[oidx] - z)
+    want = torch.nn.functional.linear(q, w_out, b_out)
+    assert float((out.cpu() - want).abs().max()) <= 2e-6 * max(1e-30, float(want.abs().max()))
 
 
 @pytest.mark.parametrize("N,C,K", [(4096, 128, 256), (1000, 128, 64), (1, 64, 32), (130, 256, 300)])

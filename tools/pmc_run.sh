@@ -8,7 +8,7 @@ while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done
 shift
 export TMPDIR=/tmp
 rm -rf "gpurun_out/pmc_$name"
-(cd /tmp && timeout -k 10 400 rocprofv3 --pmc "${ctrs[@]}" --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc_$name" -- python3 "$@" > "$GRAFT_REPO_ROOT/gpurun_out/pmc_$name.log" 2>&1) || { echo "pmc pass $name failed"; tail -5 "gpurun_out/pmc_$name.log"; exit 1; }
+(cd /tmp && timeout -k 10 400 rocprofv3 --pmc "${ctrs[@]}" --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc_$name" -- python3 "$GRAFT_REPO_ROOT/$1" "${@:2}" > "$GRAFT_REPO_ROOT/gpurun_out/pmc_$name.log" 2>&1) || { echo "pmc pass $name failed"; tail -5 "gpurun_out/pmc_$name.log"; exit 1; }
 python3 - "$name" "$match" <<'PY'
 import csv, glob, collections, sys, json
 name, match = sys.argv[1], sys.argv[2]

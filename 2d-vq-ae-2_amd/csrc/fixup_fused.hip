@@ -406,6 +406,202 @@ int launch_tiny_r(FusedP& p, hipStream_t stream) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// C = 16, fp32 (round 3): the same block with conv2 as Winograd F(2x2, 3x3), everything after conv1 in REGISTERS.
+// The kernel above runs 728 v_mfma_f32_16x16x4_f32 per 8 x 32 tile (88 conv1 on the halo + 576 conv2 + 64 conv3) -- at the
+// 256 x 256 level of cfg B (2.1 GB moved per block: 0.3 ms of HBM) the fp32 matrix pipe is the bound (0.6 ms at 100 %; measured
+// 1.12 ms).  F(2x2, 3x3) needs 16 multiplies per 2 x 2 outputs instead of 36: conv2 becomes 256 MFMAs, 408 in all.
+// What makes it cheap here is the operand layout of the 16x16x4 MFMA with the weights as the ROW operand: lane (li, q) feeds
+// B[k = q][column li] = 4 channels (4 q ..) of "column" li and receives D[4 q + r][li] = 4 output channels of the same column.
+// With column = one 2 x 2 Winograd tile (a wave owns one tile row: 16 tiles) a lane
+//   * reads the 4 x 4 input patch of ITS tile and ITS 4 channels from the t1 halo in LDS (16 x ds_read_b128),
+//   * forms B^T d B in registers (adds only): the 16 transformed values ARE the B operands of the 16 position GEMMs,
+//   * folds the 16 products through A^T . A into the 2 x 2 outputs (adds only), applies ELU: 4 pixels x 4 channels in the
+//     layout conv3's B operand wants, runs conv3 per sub-pixel, adds the residual and stores 16 bytes per pixel.
+// No LDS traffic and no barrier between conv1 and the store; U = G g G^T (16 x [16 x 16], 16 KiB) is built once per
+// (persistent) workgroup and read as linear 1 KiB fragments.  Results differ from the direct form by fp32 rounding only.
+template <int TH>
+__global__ __launch_bounds__(256, 3)
+void fixup_same_wino16_kernel(const FusedP p) {
+    constexpr int C = 16;
+    using K = FusedCfg<C, TH>;
+    constexpr int LDT = K::LDT, HP = K::HP;
+    constexpr int G1 = K::HPP / 16;                     // 16-pixel groups of the halo
+    constexpr int GPW = (G1 + 3) / 4;
+    static_assert(TH == 8, "a wave owns one Winograd tile row: 4 waves x 2 image rows");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const W1s = lds;                             // [16][LDT]
+    float* const W3s = W1s + 16 * LDT;
+    float* const Us = W3s + 16 * LDT;                   // [16 pos][16 n][16 k]
+    float* const T1 = Us + 16 * 256;                    // [HP][LDT]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, q = lane >> 4;
+
+    for (int i = tid; i < 16 * (C / 4); i += 256) {
+        const int n = i / (C / 4), c4 = i % (C / 4);
+        *reinterpret_cast<f32x4*>(W1s + n * LDT + 4 * c4) = *reinterpret_cast<const f32x4*>(p.w1 + n * C + 4 * c4);
+        *reinterpret_cast<f32x4*>(W3s + n * LDT + 4 * c4) = *reinterpret_cast<const f32x4*>(p.w3 + n * C + 4 * c4);
+    }
+    {   // U[xi * 4 + nu][n][k] = (G g G^T)[xi][nu],  g = w2[n][tap][k],  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+        const int n = tid >> 4, k = tid & 15;
+        float g[3][3], t[4][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) g[a][b] = p.w2[n * 9 * C + (3 * a + b) * C + k];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            t[0][b] = g[0][b];
+            t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+            t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+            t[3][b] = g[2][b];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            Us[(a * 4 + 0) * 256 + tid] = t[a][0];
+            Us[(a * 4 + 1) * 256 + tid] = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
+            Us[(a * 4 + 2) * 256 + tid] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
+            Us[(a * 4 + 3) * 256 + tid] = t[a][2];
+        }
+    }
+    __syncthreads();
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3, per_xcd_wg = (nwg + 7 - xcd) >> 3;
+    const int qq = p.n_tiles >> 3, rr = p.n_tiles & 7;
+    const int xcd_lo = xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq;
+    const int xcd_n = qq + (xcd < rr ? 1 : 0);
+
+    const f32x4 w1v = *reinterpret_cast<const f32x4*>(W1s + li * LDT + 4 * q);
+    const f32x4 w3v = *reinterpret_cast<const f32x4*>(W3s + li * LDT + 4 * q);
+    const float* const uf = Us + li * 16 + 4 * q;       // + pos * 256: one linear KiB per wave-wide read
+    const float* const dp = T1 + ((2 * wave) * 34 + 2 * li) * LDT + 4 * q;   // this lane's 4 x 4 patch: + (i * 34 + j) * LDT
+
+    for (int t = slot; t < xcd_n; t += per_xcd_wg) {
+        const int tile = xcd_lo + t;
+        const int txi = tile % p.tiles_x;
+        const int tyi = (tile / p.tiles_x) % p.tiles_y;
+        const int b = tile / (p.tiles_x * p.tiles_y);
+        const int ty0 = tyi * TH, tx0 = txi * 32;
+        const float* const xim = p.x + (int64_t)b * p.H * p.W * C;
+
+        // ---- P1: t1 = ELU(conv1(ELU(x + b1a) + b1b) + b2a) + b2b on the (TH + 2) x 34 halo -> LDS --------------------------------
+#pragma unroll
+        for (int gi = 0; gi < GPW; ++gi) {
+            const int g = wave + 4 * gi;
+            if (g < G1) {
+                int hp = 16 * g + li;
+                hp = hp < HP ? hp : HP - 1;
+                const int hy = hp / 34, hx = hp - 34 * hy;
+                int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
+                iy = iy < 0 ? iy + p.H : (iy >= p.H ? iy - p.H : iy);
+                ix = ix < 0 ? ix + p.W : (ix >= p.W ? ix - p.W : ix);
+                f32x4 v = *reinterpret_cast<const f32x4*>(xim + ((int64_t)iy * p.W + ix) * C + 4 * q);
+                v = v + p.b1a;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float av = elu_act(v[k]) + p.b1b;
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1v[k], av, acc, 0, 0, 0);   // D[channel 4q + r][pixel li]
+                }
+                if (16 * g + li < HP) {                 // rows past the halo are padding of the last 16-pixel group
+                    f32x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = elu_act(acc[r] + p.b2a) + p.b2b;
+                    *reinterpret_cast<f32x4*>(T1 + (16 * g + li) * LDT + 4 * q) = o;
+                }
+            }
+        }
+        // residual pixels of this lane's 2 x 2 tile: requested now, used after conv3
+        const int64_t pix = (((int64_t)b * p.H + ty0 + 2 * wave) * p.W + tx0 + 2 * li) * C + 4 * q;
+        f32x4 res[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) res[a][bb] = *reinterpret_cast<const f32x4*>(p.x + pix + ((int64_t)a * p.W + bb) * C);
+        __syncthreads();                                // t1 complete
+
+        // ---- P2: conv2 = A^T [ sum_c U .* (B^T d B) ] A, from registers --------------------------------------------------------------
+        f32x4 d[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[i][j] = *reinterpret_cast<const f32x4*>(dp + (i * 34 + j) * LDT);
+        __syncthreads();                                // every wave holds its patches: the next tile's conv1 may overwrite t1
+        f32x4 y00 = {0.f, 0.f, 0.f, 0.f}, y01 = y00, y10 = y00, y11 = y00;
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi) {
+            // row xi of B^T d:  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+            f32x4 c[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                c[j] = xi == 0 ? d[0][j] - d[2][j] : (xi == 1 ? d[1][j] + d[2][j] : (xi == 2 ? d[2][j] - d[1][j] : d[1][j] - d[3][j]));
+            f32x4 v[4];
+            v[0] = c[0] - c[2];
+            v[1] = c[1] + c[2];
+            v[2] = c[2] - c[1];
+            v[3] = c[1] - c[3];
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) {
+                const f32x4 u = *reinterpret_cast<const f32x4*>(uf + (4 * xi + nu) * 256);
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(u[k], v[nu][k], acc, 0, 0, 0);
+                // fold: Y[a][b] += A^T[a][xi] * A^T[b][nu] * acc,  A^T = [1 1 1 0; 0 1 -1 -1]
+                const int ca0 = xi <= 2 ? 1 : 0, ca1 = xi == 0 ? 0 : (xi == 1 ? 1 : -1);
+                const int cb0 = nu <= 2 ? 1 : 0, cb1 = nu == 0 ? 0 : (nu == 1 ? 1 : -1);
+                if (ca0 * cb0 != 0) y00 = y00 + acc;
+                if (ca0 * cb1 == 1) y01 = y01 + acc; else if (ca0 * cb1 == -1) y01 = y01 - acc;
+                if (ca1 * cb0 == 1) y10 = y10 + acc; else if (ca1 * cb0 == -1) y10 = y10 - acc;
+                if (ca1 * cb1 == 1) y11 = y11 + acc; else if (ca1 * cb1 == -1) y11 = y11 - acc;
+            }
+        }
+        // ---- P3: t2 = ELU(conv2 + b3a) + b3b (already conv3's B operand), conv3, * scale + bias4 + x -> global ----------------------
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                const f32x4 yv = a == 0 ? (bb == 0 ? y00 : y01) : (bb == 0 ? y10 : y11);
+                f32x4 acc3 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float tv = elu_act(yv[k] + p.b3a) + p.b3b;
+                    acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(w3v[k], tv, acc3, 0, 0, 0);
+                }
+                f32x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float tv = acc3[r] * p.scale;
+                    tv = tv + p.b4;
+                    o[r] = tv + res[a][bb][r];
+                }
+                *reinterpret_cast<f32x4*>(p.y + pix + ((int64_t)a * p.W + bb) * C) = o;
+            }
+    }
+}
+
+template <int TH>
+int launch_wino16(FusedP& p, hipStream_t stream) {
+    using K = FusedCfg<16, TH>;
+    constexpr int lds_bytes = (2 * 16 * K::LDT + 16 * 256 + K::HP * K::LDT) * (int)sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)fixup_same_wino16_kernel<TH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        attr_set = true;
+    }
+    p.tiles_x = p.W / 32;
+    p.tiles_y = p.H / TH;
+    p.n_tiles = p.B * p.tiles_x * p.tiles_y;
+    int grid = 256 * 3;
+    if (grid > p.n_tiles) grid = p.n_tiles;
+    fixup_same_wino16_kernel<TH><<<grid, 256, lds_bytes, stream>>>(p);
+    VQAE_LAUNCH_CHECK();
+    return VQAE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // C = 8 (stem-width level of the reference default model, 512x512 resolution): a VALU kernel.  With 8 channels an
 // MFMA tile is mostly padding (16x16x4: half of N, two k-steps per tap) and the block's 704 MACs per pixel fit the
 // vector ALUs: one thread per output pixel, t1 of the (TH+2) x 34 halo in LDS, the 704 weights in LDS too (read as
@@ -554,6 +750,10 @@ extern "C" int vqae_fixup_same_block_f32(const float* x, float* y, const float* 
     static const bool use32 = getenv("VQAE_FUSED_32X32") && atoi(getenv("VQAE_FUSED_32X32"));
     static const bool mfma8 = getenv("VQAE_C8_MFMA") && atoi(getenv("VQAE_C8_MFMA"));
     if (c == 8) return use32 ? launch_fused<8, 8>(p, stream) : (mfma8 ? launch_tiny<8, 8>(p, stream) : launch_c8(p, stream));
+    // fp32, C = 16: conv2 as Winograd F(2x2, 3x3) from registers (fixup_same_wino16_kernel); read per call so that tests can compare
+    // the forms inside one process
+    const char* nw = getenv("VQAE_NO_WINO16");
+    if (c == 16 && dtype == VQAE_DT_F32 && !use32 && !(nw && atoi(nw))) return launch_wino16<8>(p, stream);
     if (c == 16) return use32 ? launch_fused<16, 8>(p, stream) : launch_tiny<16, 8>(p, stream);
     return launch_fused<32, 4>(p, stream);
 }

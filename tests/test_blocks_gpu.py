@@ -357,3 +357,30 @@ def test_persistent_conv1_equals_one_shot_bitwise(amd, oracle, name, monkeypatch
             assert torch.equal(a, b), (prefix, ci)
             n += 1
     assert n >= 2
+
+
+def test_wino16_block_equals_direct_form(amd, oracle, monkeypatch):
+    """fixup_same_wino16_kernel (C = 16, fp32: conv2 as Winograd F(2x2, 3x3), everything after conv1 in registers) against the
+    direct 9-tap kernel (VQAE_NO_WINO16=1) on identical inputs, incl. several tiles per image in both directions and a batch
+    that does not fill the persistent grid: fp32 rounding only (<= 2e-5 * scale; measured ~1e-6)."""
+    g = torch.Generator().manual_seed(11)
+    C = 16
+    sc = [0.1, -0.05, 0.07, 0.02, -0.03, 0.04, 0.01, 0.9]
+    w1 = torch.randn(C, C, 1, 1, generator=g) / C ** 0.5
+    w2 = torch.randn(C, C, 3, 3, generator=g) / (9 * C) ** 0.5
+    w3 = torch.randn(C, C, 1, 1, generator=g) / C ** 0.5
+    packed = [amd.ops.pack_conv_weight(w.cuda()) for w in (w1, w2, w3)]
+    p = {"blk.branch_conv1.weight": w1, "blk.branch_conv2.weight": w2, "blk.branch_conv3.weight": w3}
+    for n, v in zip(("bias1a", "bias1b", "bias2a", "bias2b", "bias3a", "bias3b", "bias4", "scale"), sc):
+        p["blk." + n] = torch.tensor([v])
+    for (B, H, W) in ((3, 16, 64), (1, 8, 32), (2, 40, 96)):
+        x = torch.randn(B, H, W, C, generator=g).cuda()
+        monkeypatch.setenv("VQAE_NO_WINO16", "1")
+        a = amd.ops.fixup_same_block(x, *packed, sc)
+        monkeypatch.delenv("VQAE_NO_WINO16")
+        b = amd.ops.fixup_same_block(x, *packed, sc)
+        ref = oracle.fixup_block(x.permute(0, 3, 1, 2).cpu(), p, "blk", "same").permute(0, 2, 3, 1)
+        scale = float(ref.abs().max())
+        e_ab, e_b = float((a - b).abs().max()) / scale, float((b.cpu() - ref).abs().max()) / scale
+        record_parity("wino16_vs_direct", B=B, H=H, W=W, rel_err_vs_direct=e_ab, rel_err_vs_oracle=e_b)
+        assert e_ab <= 2e-5 and e_b <= 2e-5, (B, H, W, e_ab, e_b)

@@ -267,6 +267,17 @@ __global__ void embed_code_kernel(const T* __restrict__ idx, const float4* __res
     }
 }
 
+template <typename T>
+__global__ void embed_code_scalar_kernel(const T* __restrict__ idx, const float* __restrict__ embed, int64_t total, int D, int K,
+                                         float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i / D;
+        int64_t k = (int64_t)idx[n];
+        k = k < 0 ? 0 : (k >= K ? K - 1 : k);
+        out[i] = embed[k * D + (i - n * D)];
+    }
+}
+
 // ---- training-mode bookkeeping (vq.py:47-74) -------------------------------------------------
 // One block per code: deterministic segmented sum.  Each of the 16 waves scans a contiguous slice of
 // idx (ballot over 64 rows at a time) and adds the matching rows in ascending row order; the 16
@@ -404,6 +415,22 @@ int vq_write_idx(const int* idx32, int64_t N, void* idx_out, int idx_dtype, hipS
 }
 }  // namespace vqae
 
+namespace {
+__global__ void vq_pad_rows_kernel(const float* __restrict__ src, int64_t n, int d, int dp, float* __restrict__ dst) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n * dp; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / dp;
+        const int c = (int)(i - r * dp);
+        dst[i] = c < d ? src[r * d + c] : 0.f;
+    }
+}
+__global__ void vq_unpad_rows_kernel(const float* __restrict__ src, int64_t n, int d, int dp, float* __restrict__ dst) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n * d; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / d;
+        dst[i] = src[r * dp + (i - r * d)];
+    }
+}
+}  // namespace
+
 extern "C" size_t vqae_vq_workspace_bytes(int64_t n_rows, int n_codes, int dim) {
     const int64_t Kpad = vqae::round_up(n_codes, VQ_TK);
     const size_t ftab = (dim == 256) ? (size_t)vqae::round_up((int64_t)vqae::vq_filter_table_bytes(n_codes, dim), 256) : 0;
@@ -418,11 +445,34 @@ extern "C" int vqae_vq_forward_f32(const float* z, const float* embed, int64_t N
     VQAE_REQUIRE(N >= 0 && N < (1ll << 31), VQAE_ERR_INVALID, "vq_forward: n_rows %lld out of range", (long long)N);
     VQAE_REQUIRE(N == 0 || (z && embed && idx_out && ws), VQAE_ERR_INVALID, "vq_forward: null pointer");
     VQAE_REQUIRE(K >= 1 && K <= 65536, VQAE_ERR_UNSUPPORTED, "vq_forward: n_codes %d unsupported", K);
-    VQAE_REQUIRE(D >= 4 && D % 4 == 0 && D <= 4096, VQAE_ERR_UNSUPPORTED, "vq_forward: dim %d must be a multiple of 4", D);
+    VQAE_REQUIRE(D >= 1 && D <= 4096, VQAE_ERR_UNSUPPORTED, "vq_forward: dim %d unsupported (1 .. 4096)", D);
     VQAE_REQUIRE(idx_dtype != VQAE_IDX_U8 || K <= 256, VQAE_ERR_INVALID, "vq_forward: u8 indices need K <= 256");
     if (N == 0) {
         if (loss) VQAE_HIP_CHECK(hipMemsetAsync(loss, 0, sizeof(float), stream));
         return VQAE_OK;
+    }
+    if (D % 4 != 0) {
+        // The reference takes any embedding_dim (vq.py:121-129).  The kernels move rows as 16-byte vectors, so such a call runs on
+        // zero-padded copies of z and of the codebook (stream-ordered scratch): a zero channel adds fma(0, 0, acc) = acc to every
+        // distance -- bit for bit the same sums, indices, q -- and the loss (a mean over N * D elements) is rescaled by Dp / D.
+        const int Dp = (int)vqae::round_up(D, 4);
+        float *zp = nullptr, *ep = nullptr, *qp = nullptr;
+        void* wsp = nullptr;
+        VQAE_HIP_CHECK(hipMallocAsync((void**)&zp, (size_t)N * Dp * 4, stream));
+        VQAE_HIP_CHECK(hipMallocAsync((void**)&ep, (size_t)K * Dp * 4, stream));
+        VQAE_HIP_CHECK(hipMallocAsync((void**)&wsp, vqae_vq_workspace_bytes(N, K, Dp), stream));
+        if (q) VQAE_HIP_CHECK(hipMallocAsync((void**)&qp, (size_t)N * Dp * 4, stream));
+        vq_pad_rows_kernel<<<(unsigned)std::min<int64_t>(vqae::ceil_div(N * Dp, 256), 65536), 256, 0, stream>>>(z, N, D, Dp, zp);
+        vq_pad_rows_kernel<<<(unsigned)std::min<int64_t>(vqae::ceil_div((int64_t)K * Dp, 256), 65536), 256, 0, stream>>>(embed, K, D, Dp, ep);
+        VQAE_LAUNCH_CHECK();
+        int rc = vqae_vq_forward_f32(zp, ep, N, K, Dp, commitment * ((float)Dp / (float)D), idx_out, idx_dtype, qp, loss, margin, wsp, stream_);
+        if (rc == VQAE_OK && q) {
+            vq_unpad_rows_kernel<<<(unsigned)std::min<int64_t>(vqae::ceil_div(N * D, 256), 65536), 256, 0, stream>>>(qp, N, D, Dp, q);
+            if (hipGetLastError() != hipSuccess) rc = vqae::fail(VQAE_ERR_HIP, "vq_forward: unpad launch failed");
+        }
+        (void)hipFreeAsync(zp, stream); (void)hipFreeAsync(ep, stream); (void)hipFreeAsync(wsp, stream);
+        if (qp) (void)hipFreeAsync(qp, stream);
+        return rc;
     }
     const int Kpad = (int)vqae::round_up(K, VQ_TK);
     VqWorkspace w = carve(ws, N, K, D);
@@ -483,8 +533,20 @@ extern "C" int vqae_embed_code_f32(const void* idx, int idx_dtype, const float* 
                                    float* out, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     VQAE_REQUIRE(idx && embed && out, VQAE_ERR_INVALID, "embed_code: null pointer");
-    VQAE_REQUIRE(D % 4 == 0, VQAE_ERR_UNSUPPORTED, "embed_code: dim %d must be a multiple of 4", D);
     if (N == 0) return VQAE_OK;
+    if (D % 4 != 0) {                                    // any embedding_dim (vq.py:44-45): one element per thread
+        const int64_t total = N * D;
+        const unsigned nb = (unsigned)std::min<int64_t>(65536, vqae::ceil_div(total, 256));
+        switch (idx_dtype) {
+            case VQAE_IDX_I64: embed_code_scalar_kernel<int64_t><<<nb, 256, 0, stream>>>((const int64_t*)idx, embed, total, D, K, out); break;
+            case VQAE_IDX_U8: embed_code_scalar_kernel<uint8_t><<<nb, 256, 0, stream>>>((const uint8_t*)idx, embed, total, D, K, out); break;
+            case VQAE_IDX_U16: embed_code_scalar_kernel<uint16_t><<<nb, 256, 0, stream>>>((const uint16_t*)idx, embed, total, D, K, out); break;
+            case VQAE_IDX_I32: embed_code_scalar_kernel<int32_t><<<nb, 256, 0, stream>>>((const int32_t*)idx, embed, total, D, K, out); break;
+            default: return vqae::fail(VQAE_ERR_INVALID, "embed_code: bad idx_dtype %d", idx_dtype);
+        }
+        VQAE_LAUNCH_CHECK();
+        return VQAE_OK;
+    }
     const int64_t total4 = N * (D / 4);
     const int nblk = (int)std::min<int64_t>(4096, vqae::ceil_div(total4, 256));
     switch (idx_dtype) {

@@ -60,8 +60,6 @@ class PreActFixupResBlock(nn.Module):
                  activation=None, conv_conf=None, n_layers: Optional[int] = None):
         super().__init__()
         assert mode in _MODES                                              # conv_block.py:148
-        if mode == "out":
-            raise NotImplementedError("mode 'out' is unused by Encoder/Decoder and not implemented")
         max_channels = max(in_channels, out_channels)
         assert isclose(max_channels % bottleneck_divisor, 0), (          # conv_block.py:152-154
             f"residual channels: {max_channels} not divisible by bottleneck divisor: {bottleneck_divisor}!")
@@ -72,9 +70,10 @@ class PreActFixupResBlock(nn.Module):
             if not str(tgt).endswith("ELU") or float(alpha) != 1.0:
                 raise NotImplementedError(f"only ELU(alpha=1) is implemented (activation/elu.yaml); got {tgt}")
         cc = (conv_conf or {}).get(mode, {}) if conv_conf is not None else {}
-        want2 = {"same": (3, 1, 1, True), "down": (2, 2, 0, False), "up": (1, 1, 0, False)}[mode]
+        # branch_conv2: same2d / out2d (3x3 s1 p1, circular by the block conf), down2d (2x2 s2), up2dresize (bicubic x2 + 1x1)
+        want2 = {"same": (3, 1, 1, True), "out": (3, 1, 1, True), "down": (2, 2, 0, False), "up": (1, 1, 0, False)}[mode]
         got2 = _conv_kind(cc.get("branch_conv2"), want2)
-        if got2[:3] != want2[:3] or (mode == "same" and not got2[3]):
+        if got2[:3] != want2[:3] or (mode in ("same", "out") and not got2[3]):
             raise NotImplementedError(f"branch_conv2 {got2} for mode '{mode}' is not the implemented {want2}")
         for nm in ("branch_conv1", "branch_conv3"):
             if _conv_kind(cc.get(nm), (1, 1, 0, False))[:3] != (1, 1, 0):
@@ -88,10 +87,14 @@ class PreActFixupResBlock(nn.Module):
         self.branch_conv2 = _Weight(branch, branch, want2[0])
         self.branch_conv3 = _Weight(out_channels, branch, 1)
         if not (mode in ("same", "out") and in_channels == out_channels):  # conv_block.py:180-191
-            if mode == "same":
-                raise NotImplementedError("'same' blocks with in_channels != out_channels are not implemented")
+            # skip_conv: down2d (2x2 s2) / up2dresize (1x1 after the resize) / proj2d (1x1, 'same') / out2d (3x3 s1 p1 ZERO padding:
+            # pre_activation_fixup.yaml sets padding_mode 'circular' for out.branch_conv2 only)
+            want_s = {"down": (2, 2, 0), "up": (1, 1, 0), "same": (1, 1, 0), "out": (3, 1, 1)}[mode]
+            got_s = _conv_kind(cc.get("skip_conv"), want_s + (False,))
+            if got_s[:3] != want_s or (mode == "out" and got_s[3]):
+                raise NotImplementedError(f"skip_conv {got_s} for mode '{mode}' is not the implemented {want_s} (zero padding)")
             self.bias1c, self.bias1d = (nn.Parameter(torch.zeros(1)) for _ in range(2))
-            self.skip_conv = _Weight(out_channels, in_channels, 2 if mode == "down" else 1)
+            self.skip_conv = _Weight(out_channels, in_channels, want_s[0])
         else:
             self.skip_conv = None
         if n_layers is not None:
@@ -110,7 +113,7 @@ class PreActFixupResBlock(nn.Module):
         """conv_block.py:196-216 on an NHWC tensor (the block's native layout)."""
         f = lambda p: float(p.detach())
         br = self.branch_channels
-        if (self.mode == "same" and br == self.in_channels
+        if (self.mode in ("same", "out") and self.skip_conv is None and br == self.in_channels
                 and ops.fixup_same_supported(self.in_channels, x.shape[1], x.shape[2])):
             return ops.fixup_same_block(x, self.branch_conv1.packed(), self.branch_conv2.packed(),
                                         self.branch_conv3.packed(),
@@ -118,10 +121,17 @@ class PreActFixupResBlock(nn.Module):
                                          f(self.bias3a), f(self.bias3b), f(self.bias4), f(self.scale)])
         t = ops.conv2d(x, self.branch_conv1.packed(), br, 1, pre=(f(self.bias1a), f(self.bias1b)),
                        act=(f(self.bias2a), f(self.bias2b)))
-        if self.mode == "same":
+        if self.mode in ("same", "out"):
             t = ops.conv2d(t, self.branch_conv2.packed(), br, 3, 1, 1, L.PAD_CIRCULAR,
                            act=(f(self.bias3a), f(self.bias3b)))
-            skip = x
+            if self.skip_conv is None:
+                skip = x
+            elif self.mode == "same":                                       # proj2d: skip_conv(inp + bias1c) + bias1d
+                skip = ops.conv2d(x, self.skip_conv.packed(), self.out_channels, 1, pre=(f(self.bias1c),),
+                                  bias_s=f(self.bias1d))
+            else:                                                           # out2d: 3x3, zero padding
+                skip = ops.conv2d(x, self.skip_conv.packed(), self.out_channels, 3, 1, 1, L.PAD_ZEROS,
+                                  pre=(f(self.bias1c),), bias_s=f(self.bias1d))
         elif self.mode == "down":
             t = ops.conv2d(t, self.branch_conv2.packed(), br, 2, 2, 0, act=(f(self.bias3a), f(self.bias3b)))
             skip = ops.conv2d(x, self.skip_conv.packed(), self.out_channels, 2, 2, 0, pre=(f(self.bias1c),),

@@ -69,7 +69,9 @@ size_t vqae_vq_workspace_bytes(int64_t n_rows, int n_codes, int dim);
  *   q_dev     [n_rows][dim] fp32 or NULL;  loss_dev  one fp32 or NULL
  *   margin_dev [n_rows] fp32 or NULL: relative gap between best and second-best 4th-power sums
  *   workspace_dev: vqae_vq_workspace_bytes(...) bytes.
- * Errors: dim not a multiple of 4, n_codes < 1 or > 65536 -> VQAE_ERR_UNSUPPORTED. */
+ *   dim: any 1 .. 4096 like the reference; a dim that is not a multiple of 4 runs on zero-padded copies of z and of the
+ *   codebook (stream-ordered scratch): the same sums, indices and q bit for bit.
+ * Errors: dim < 1 or > 4096, n_codes < 1 or > 65536 -> VQAE_ERR_UNSUPPORTED. */
 int vqae_vq_forward_f32(const float* z_dev, const float* embed_dev, int64_t n_rows, int n_codes, int dim,
                         float commitment_cost, void* idx_dev, int idx_dtype, float* q_dev, float* loss_dev,
                         float* margin_dev, void* workspace_dev, void* stream);

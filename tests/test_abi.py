@@ -45,8 +45,10 @@ def test_error_convention_without_gpu(amd):
     with pytest.raises(NotImplementedError):      # cin % 8 != 0 -> VQAE_ERR_UNSUPPORTED
         L.check(lib.vqae_conv2d_f32(ctypes.byref(a), one, one, None, None, one, None))
     assert b"cin" in lib.vqae_last_error()
-    with pytest.raises(NotImplementedError):      # dim % 4 != 0
-        L.check(lib.vqae_vq_forward_f32(one, one, 16, 4, 6, 1.0, one, 0, None, None, None, one, None))
+    with pytest.raises(NotImplementedError):      # dim out of range (any 1 .. 4096 is taken, like the reference)
+        L.check(lib.vqae_vq_forward_f32(one, one, 16, 4, 5000, 1.0, one, 0, None, None, None, one, None))
+    with pytest.raises(NotImplementedError):      # n_codes out of range
+        L.check(lib.vqae_vq_forward_f32(one, one, 16, 70000, 8, 1.0, one, 0, None, None, None, one, None))
 
 
 def test_ops_refuse_cpu_tensors(amd):

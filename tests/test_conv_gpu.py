@@ -129,6 +129,26 @@ def test_bicubic_up2(amd, oracle, shape):
     close(y, oracle.bicubic_up2(x + 0.125), 1e-6)                     # ATen's own kernel: <= 1 ulp-ish
 
 
+@pytest.mark.parametrize("cin,cout,bias,shape", [(32, 16, False, (2, 12, 20)), (8, 8, True, (1, 5, 7)), (64, 32, False, (3, 16, 16))])
+def test_resize_conv2d_mirror_matches_upsample_then_conv(amd, cin, cout, bias, shape):
+    """The stand-alone mirror vqae_amd.layers.conv.ResizeConv2D (reference vq_ae/layers/conv.py:4-11: nn.Conv2d whose forward
+    is conv(nn.Upsample(scale_factor=2, mode='bicubic')(x))) against exactly that composition in PyTorch fp32 on the CPU."""
+    from vqae_amd.layers.conv import ResizeConv2D
+    torch.manual_seed(cin + cout)
+    m = ResizeConv2D(cin, cout, kernel_size=1, bias=bias)
+    ref_conv = torch.nn.Conv2d(cin, cout, 1, bias=bias)
+    ref_conv.load_state_dict(m.state_dict())                           # same parameter names as nn.Conv2d: weight (, bias)
+    B, H, W = shape
+    x = torch.randn(B, cin, H, W)
+    with torch.no_grad():
+        want = ref_conv(torch.nn.Upsample(scale_factor=2, mode="bicubic")(x))
+        got = m.cuda()(x.cuda()).cpu()
+    assert got.shape == want.shape == (B, cout, 2 * H, 2 * W)
+    close(got, want, 2e-5)
+    with pytest.raises(NotImplementedError):
+        ResizeConv2D(cin, cout, kernel_size=3, padding=1)
+
+
 def test_layout_roundtrip_and_helpers(amd, oracle):
     x = torch.randn(3, 20, 6, 10)
     y = amd.ops.nchw_to_nhwc(x.cuda())
@@ -225,3 +245,31 @@ def test_stem16_mfma_stems_match_autocast_reference(amd, oracle, tag, dt, c0, H,
     with torch.autocast("cpu", dtype=dt):
         ref = F.conv2d(xo, wo, bo, padding=1)
     check(amd.ops.conv3x3_direct(nhwc(xo).cuda(), wo.cuda(), bo.cuda(), dtype=tag), ref)
+
+
+@pytest.mark.parametrize("mode,cin,cout,shape", [("same", 16, 32, (2, 8, 32)), ("same", 32, 16, (1, 12, 20)), ("out", 16, 8, (2, 8, 32)),
+                                                 ("out", 16, 16, (2, 8, 32)), ("out", 24, 40, (1, 6, 10))])
+def test_fixup_block_shape_variants_match_oracle(amd, oracle, mode, cin, cout, shape):
+    """Block shapes the reference class accepts beyond what Encoder / Decoder compose (conv_block.py:180-191 with
+    pre_activation_fixup.yaml): 'same' with in_channels != out_channels (1x1 skip_conv on inp + bias1c, + bias1d) and mode 'out'
+    (3x3 circular branch_conv2; 3x3 ZERO-padded skip_conv, or the identity when the channel counts agree): the mirror module
+    against the oracle's restatement of PreActFixupResBlock.forward (conv_block.py:196-216), fp32."""
+    from vqae_amd.layers.conv_block import PreActFixupResBlock
+    torch.manual_seed(cin * 100 + cout)
+    m = PreActFixupResBlock(cin, cout, mode, bottleneck_divisor=1, n_layers=4)
+    with torch.no_grad():
+        for n, prm in m.named_parameters():
+            if n.endswith("branch_conv3.weight"):
+                prm.normal_(0.0, 1.0 / prm.shape[1] ** 0.5)                # the reference zero-initialises conv3: make the branch count
+            elif prm.numel() == 1:
+                prm.copy_(torch.rand(1) * 0.4 - 0.2 + (1.0 if n == "scale" else 0.0))
+    assert (m.skip_conv is None) == (cin == cout)
+    if m.skip_conv is not None:
+        assert m.skip_conv.weight.shape[-1] == (1 if mode == "same" else 3)
+    p = {"blk." + k: v.detach().clone() for k, v in m.state_dict().items()}
+    B, H, W = shape
+    x = torch.randn(B, cin, H, W)
+    want = oracle.fixup_block(x, p, "blk", mode)
+    got = m.cuda()(x.cuda()).cpu()
+    assert got.shape == want.shape == (B, cout, H, W)
+    close(got, want, 2e-5)

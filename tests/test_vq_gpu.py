@@ -45,6 +45,22 @@ def test_vq_ragged_sizes(amd, oracle, N, D, K):
     assert abs(loss - ref_loss) <= 2e-6 * max(ref_loss, 1e-30)
 
 
+@pytest.mark.parametrize("N,D,K", [(1000, 6, 40), (257, 13, 300), (64, 3, 5), (130, 130, 64)])
+def test_vq_any_embedding_dim(amd, oracle, N, D, K):
+    """embedding_dim not a multiple of 4 (the reference accepts any, vq.py:121-129): zero-padded copies inside the call;
+    indices / q identical to the oracle's, loss a mean over the REAL N * D elements; embed_code on such a codebook."""
+    z, embed = oracle.make_vq_case(D, K, max(N, 128), seed=9, adversarial=K >= 32)
+    z = z[:N].contiguous()
+    q, idx, loss, margin = run_hip(amd, z, embed)
+    oidx, _, _ = oracle.vq_argmin_p4(z, embed)
+    assert torch.equal(idx, oidx)
+    assert torch.equal(q, z + (embed[oidx] - z))
+    ref_loss = float(((z - embed[oidx]) ** 2).double().mean())
+    assert abs(loss - ref_loss) <= 2e-6 * max(ref_loss, 1e-30)
+    got = amd.ops.embed_code(oidx.cuda(), embed.cuda()).cpu()
+    assert torch.equal(got, embed[oidx])
+
+
 def test_vq_empty(amd):
     q, idx, loss, _ = amd.ops.vq_forward(torch.zeros(0, 8).cuda(), torch.randn(4, 8).cuda(), want_margin=True)
     torch.cuda.synchronize()

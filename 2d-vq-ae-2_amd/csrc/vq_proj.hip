@@ -540,7 +540,7 @@ int launch_vq_proj16(const VqProjK& k, hipStream_t stream) {
     // VQAE_VQ16_WPS: waves per SIMD the kernel is compiled and launched for.  3 keeps the register prefetch of the next step's
     // rows (256-thread workgroups, 3 per CU); 4 drops it for more resident waves (512-thread workgroups, 2 per CU)
     static const int wps = getenv("VQAE_VQ16_WPS") ? atoi(getenv("VQAE_VQ16_WPS")) : 4;
-    const int nwv = wps >= 4 ? 8 : 4;
+    const int nwv = wps >= 5 ? 10 : (wps == 4 ? 8 : 4);
     const size_t lds_bytes = ((size_t)((k.K + 3) & ~3) * PD + (size_t)C * 17 + C + 16 + 16 + (size_t)C * 9) * sizeof(float)
                              + (size_t)nwv * (16 * PD * 4 + 16 * 8 * 2 + VP16_CAP * 4 + 16) + (use_filter ? (size_t)(k.K / 16) * 1024 : 0);
     static int n_cu = 0;
@@ -554,7 +554,8 @@ int launch_vq_proj16(const VqProjK& k, hipStream_t stream) {
     const int wg_per_cu = std::max(1, std::min(wps >= 4 ? 2 : 3, (int)(160 * 1024 / (lds_bytes + 256))));
     const unsigned grid = (unsigned)std::min<int64_t>(vqae::ceil_div(n_units, nwv), (int64_t)n_cu * wg_per_cu);
     vqae::ProfScope prof(vqae::PROF_VQ_TIER1, stream, (double)k.N * (29.0 * k.K + 4.0 * PD * k.C));
-    if (wps >= 4) vq_proj16_kernel<C, DT, 4, false, 8><<<grid, 512, lds_bytes, stream>>>(k, n_units, use_filter);
+    if (wps >= 5) vq_proj16_kernel<C, DT, 5, false, 10><<<grid, 640, lds_bytes, stream>>>(k, n_units, use_filter);
+    else if (wps == 4) vq_proj16_kernel<C, DT, 4, false, 8><<<grid, 512, lds_bytes, stream>>>(k, n_units, use_filter);
     else vq_proj16_kernel<C, DT, 3, true, 4><<<grid, 256, lds_bytes, stream>>>(k, n_units, use_filter);
     prof.done();
     VQAE_LAUNCH_CHECK();

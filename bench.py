@@ -68,10 +68,18 @@ def kernel_source_hash(files):
 
 def pmc_traffic(key):
     """HBM bytes per launch of the dominant kernel from separate rocprofv3 --pmc passes (FETCH_SIZE doubled per
-    MI355X_MICROARCH.md, + WRITE_SIZE), as recorded in profiles/r02_pmc_traffic.json by tools/pmc_traffic.sh.  Each
+    MI355X_MICROARCH.md, + WRITE_SIZE), as recorded in profiles/r0N_pmc_traffic.json by tools/pmc_traffic.py.  Each
     entry carries the hash of the kernel sources it was measured on; a figure for other code is refused (null)."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))[key]
+        d = None
+        for rnd in ("r03", "r02"):                  # newest round first; an entry is only valid for the sources it names
+            path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
+            if os.path.exists(path) and key in json.load(open(path)):
+                d = json.load(open(path))[key]
+                if d["source_hash"] == kernel_source_hash(d["sources"]):
+                    break
+        if d is None:
+            raise KeyError(key)
         if d["source_hash"] != kernel_source_hash(d["sources"]):
             return None, f"stale: measured on sources {d['source_hash']}, kernel has changed since"
         return d["bytes_per_launch"], f"rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, sources {d['source_hash']}"
@@ -268,7 +276,7 @@ def run_leg(args, ctx, headline):
                                    "hbm_achieved_gbs": round(hbm_bytes / (avg_ms * 1e-3) / 1e9, 1),
                                    "hbm_frac": round(hbm_bytes / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
             elif args.prof_class == 2:
-                res["roofline"] = {"kernel": "fixup_conv1_kernel<128> (stand-alone 1x1 conv1 at the head of a block chain; the "
+                res["roofline"] = {"kernel": "fixup_conv1p_kernel<128> (stand-alone 1x1 conv1 at the head of a block chain, persistent form; the "
                                              "other 1x1 convs run inside the fused trunk kernel)", "bound": "mfma",
                                    "achieved": round(alg / (avg_ms * 1e-3) / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                                    "unit": "TFLOP/s", "traffic": None, "launches": k_n.value,
@@ -277,7 +285,7 @@ def run_leg(args, ctx, headline):
                 # fused projected quantiser (csrc/vq_proj.hip): one pass over the C-channel activation.  Algorithmic HBM
                 # bytes per row: C*4 read (x) + C*4 written (proj_out(q)) + 32 (z, kept for tier 2 / the loss) + 4 (index).
                 byts = M * (2.0 * C * 4 + 36.0)
-                res["roofline"] = {"kernel": "vq_proj_fused_kernel (proj_in + p=4 argmin + lookup + proj_out, projection_dim 8)",
+                res["roofline"] = {"kernel": "vq_proj16_kernel / vq_proj_fused_kernel (proj_in + p=4 argmin + lookup + proj_out in one pass, projection_dim 8)",
                                    "bound": "hbm", "achieved": round(byts / (avg_ms * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS,
                                    "unit": "GB/s", "traffic": None, "launches": k_n.value, "avg_ms": round(avg_ms, 4),
                                    "alg_bytes_per_launch": byts, "valu_ops_per_launch": alg,

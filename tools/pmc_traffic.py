@@ -2,7 +2,7 @@
 """HBM traffic per launch of the dominant (trunk block) kernel from two rocprofv3 --pmc passes over a short bench.py run
 (FETCH_SIZE and WRITE_SIZE cannot share a pass: MI355X_MICROARCH.md "rocprofv3 PMC slots"), corrected as that guide
 prescribes (FETCH_SIZE x2 on gfx950, KiB units), stamped with the hash of the kernel sources it was measured on, and
-merged into profiles/r02_pmc_traffic.json under the key <config>_<dtype>_B<batch> that bench.py looks up.
+merged into profiles/<round>_pmc_traffic.json (round = $VQAE_ROUND, default r03) under the key <config>_<dtype>_B<batch> that bench.py looks up.
 
     python tools/pmc_traffic.py --config B --dtype f32 --batch 256          (on the GPU box)
 """
@@ -17,7 +17,7 @@ def one_pass(counter, bench_args, tag):
     subprocess.call(["rm", "-rf", out])
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["timeout", "-k", "10", "300", "rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out,
-           "--", sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline"] + bench_args
+           "--", sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs"] + bench_args
     subprocess.check_call(cmd, cwd="/tmp", env=env, stdout=open(out + ".log", "w"), stderr=subprocess.STDOUT)
     rows = []
     for f in glob.glob(out + "/*/*_counter_collection.csv"):
@@ -52,7 +52,8 @@ def main():
         tot[counter] = sum(float(r["Counter_Value"]) for r in rows) / len(rows) * 1024.0     # KiB -> bytes
         tot["launches"] = len(rows)
     from bench import kernel_source_hash
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    rnd = os.environ.get("VQAE_ROUND", "r03")
+    path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
     d = json.load(open(path)) if os.path.exists(path) else {}
     d[f"{a.config}_{a.dtype}_B{a.batch}"] = {
         "kernel": pat.rstrip(", ") + ", ...>", "fetch_size_bytes_raw": tot["FETCH_SIZE"], "write_size_bytes": tot["WRITE_SIZE"],
@@ -61,7 +62,7 @@ def main():
         "sources": sources, "source_hash": kernel_source_hash(sources)}
     json.dump(d, open(path, "w"), indent=1)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    json.dump(d, open(os.path.join(ROOT, "gpurun_out", "r02_pmc_traffic.json"), "w"), indent=1)
+    json.dump(d, open(os.path.join(ROOT, "gpurun_out", f"{rnd}_pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(d[f"{a.config}_{a.dtype}_B{a.batch}"]))
 
 

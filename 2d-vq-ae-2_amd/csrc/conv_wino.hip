@@ -82,6 +82,14 @@ template <int C> struct WinoCfg {
     static constexpr int WN = C / (32 * NI);           //        waves along the channels, NW / WN along the pixels
     static constexpr int MI = PX / ((NW / WN) * 32);   //        32-pixel tiles per wave (MI * NI = 4 accumulators)
     static constexpr int LDS_BYTES = PX * LDT * 4;     // V[4][TILES][LDT] and T[PX][LDT] overlay each other
+#ifdef VQAE_WINO_PREF_ALL
+    static constexpr int PREF = 1;
+#else
+    // C <= 64: the first half of the NEXT pass's input rows is requested before this pass's MFMAs (64 registers in flight).  These
+    // levels move as many bytes per tile as C = 128 with 1/4 (C = 32) or 1/2 (C = 64) of the matrix work, and without it a tile
+    // takes HBM time PLUS matrix time (round 3).  At C = 128 the same prefetch measured slower (section 4, negative results).
+    static constexpr int PREF = C <= 64 ? 1 : 0;
+#endif
 };
 
 // Fragment order of a [C n][C k] matrix: element (n, k) of the 32-row tile n >> 5 and 8-wide k-slice k >> 3 goes to
@@ -113,6 +121,7 @@ void wino_trunk_kernel(const WinoK p) {
     };
     constexpr int W = K::W, PX = K::PX, TC = K::TC, NS = K::NS, KS = K::KS, C4 = K::C4, RP = K::RP, LDT = K::LDT, WN = K::WN;
     constexpr int MI = K::MI, NI = K::NI;
+    constexpr bool PREF = K::PREF && !WIDE;                           // column-blocked grids carry more geometry: no registers left for it
     constexpr int STEPS = 4 * KS;                                    // k-slices per pass (4 nu)
     extern __shared__ __attribute__((aligned(16))) float lds[];      // V[4][TILES][LDT]  /  T[PX][LDT]
     const int tid = threadIdx.x;
@@ -235,6 +244,7 @@ void wino_trunk_kernel(const WinoK p) {
             bq[s] = *reinterpret_cast<const f32x4*>(ux + WB(s));
         __syncthreads();
         STAMP(14 + 4 * xi);
+        if (PREF && xi < 3) tr_load(xi + 1, 0);                     // in flight under this pass's MFMAs (v is dead until then)
         f32x4 aq[2];
         aq[0] = *reinterpret_cast<const f32x4*>(af);
 #pragma unroll
@@ -281,7 +291,10 @@ void wino_trunk_kernel(const WinoK p) {
         // (0.499 vs 0.478 ms per launch), as did a longer weight-fragment prefetch: more loads in flight per CU back
         // up the vector-memory queue and the in-order wave stalls at issue, MFMAs included.  The partner workgroup of
         // the CU covers this wait.
-        if (xi < 3) { tr_load(xi + 1, 0); tr_combine(xi + 1, 0); tr_load(xi + 1, 1); tr_combine(xi + 1, 1); }
+        if (xi < 3) {
+            if (!PREF) tr_load(xi + 1, 0);
+            tr_combine(xi + 1, 0); tr_load(xi + 1, 1); tr_combine(xi + 1, 1);
+        }
         STAMP(1 + xi);
     }
 

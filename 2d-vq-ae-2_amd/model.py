@@ -91,6 +91,10 @@ class _NativeMixin:
         if owner is not None and owner() is not None:
             return owner().native()
         dt = self._autocast_dtype()
+        if dt is not None and self._spec().block == "mbconv":          # MBConv kernels are fp32 only: see NativeVQAE.with_dtype
+            import warnings
+            warnings.warn("vqae_amd: MBConv models run in fp32; the surrounding torch.autocast is ignored", stacklevel=3)
+            dt = None
         sig = self._weights_signature()
         if self._native is None or self._native.get("sig") != sig:
             for k, v in (self._native or {}).items():

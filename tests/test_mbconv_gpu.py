@@ -181,6 +181,14 @@ def test_mbconv_native_forward_matches_reference_fixture(amd, oracle):
     assert float((out_m - out).abs().max()) <= 1e-5 and abs(float(loss_m) - float(loss)) <= 1e-5 * float(loss)
     with pytest.raises(NotImplementedError):                       # MBConv handles are fp32 only
         amd.NativeVQAE(amd.SPECS["tinyM"], p, compute_dtype="bf16")
+    # ... so the reference's extraction default (fp16 autocast, extract_embeddings.py:124-125) is answered by the fp32 handle, with a
+    # warning, instead of failing: run_eval's defaults work on an EfficientNetV2-style model
+    with pytest.warns(UserWarning, match="MBConv models run in fp32"):
+        assert nat.with_dtype(torch.float16) is nat
+    with pytest.warns(UserWarning, match="MBConv models run in fp32"):
+        with torch.autocast("cuda", dtype=torch.float16):
+            (q_a,), (idx_a,), _ = model.encoder(x)
+    assert torch.equal(idx_a, idx)
 
 
 def test_mbconv_cfgB_size_matches_reference_fixture(amd, oracle):

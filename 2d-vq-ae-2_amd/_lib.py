@@ -68,6 +68,8 @@ SYMBOLS = {
     "vqae_vq_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "vqae_vq_forward_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_int, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vqae_vq_forward_p_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_void_p]),
     "vqae_vq_projected_workspace_bytes": (c_size_t, [c_int64]),
     "vqae_vq_projected_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
                                       c_float, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

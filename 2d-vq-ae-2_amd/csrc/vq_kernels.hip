@@ -42,6 +42,18 @@ __device__ __forceinline__ void merge_best(float& b1, int& i1, float& b2, float 
     if (other_wins) { b1 = ob1; i1 = oi1; }
 }
 
+// P = the Minkowski exponent = inputs.dim() (vq.py:121-129): 4 for the 2-D model's NCHW activations, 3 / 5 for [B, D, L] /
+// [B, D, d, h, w] inputs.  One term is |x - e|^P in fp32: P = 4: d2 = d * d, fma(d2, d2, .); 3: fma(d2, |d|, .); 5: fma(d2 * d2, |d|, .).
+template <int P>
+__device__ __forceinline__ float vq_term(float x, float e, float acc) {
+    float d = x - e;
+    const float d2 = d * d;
+    if (P == 4) return __builtin_fmaf(d2, d2, acc);
+    if (P == 3) return __builtin_fmaf(d2, __builtin_fabsf(d), acc);
+    return __builtin_fmaf(d2 * d2, __builtin_fabsf(d), acc);
+}
+
+template <int P>
 __global__ __launch_bounds__(VQ_WAVES * 64)
 void vq_tier1_kernel(const float* __restrict__ z, const float* __restrict__ eT, int64_t N, int K, int Kpad,
                      int D, float thr, int* __restrict__ idx32, float* __restrict__ margin,
@@ -110,11 +122,10 @@ void vq_tier1_kernel(const float* __restrict__ z, const float* __restrict__ eT, 
 #pragma unroll
                         for (int r = 0; r < VQ_RM; ++r) {
                             const float x = (j == 0) ? xv[r].x : (j == 1) ? xv[r].y : (j == 2) ? xv[r].z : xv[r].w;
-                            float d;
-                            d = x - e.x; d = d * d; acc[r][0] = __builtin_fmaf(d, d, acc[r][0]);
-                            d = x - e.y; d = d * d; acc[r][1] = __builtin_fmaf(d, d, acc[r][1]);
-                            d = x - e.z; d = d * d; acc[r][2] = __builtin_fmaf(d, d, acc[r][2]);
-                            d = x - e.w; d = d * d; acc[r][3] = __builtin_fmaf(d, d, acc[r][3]);
+                            acc[r][0] = vq_term<P>(x, e.x, acc[r][0]);
+                            acc[r][1] = vq_term<P>(x, e.y, acc[r][1]);
+                            acc[r][2] = vq_term<P>(x, e.z, acc[r][2]);
+                            acc[r][3] = vq_term<P>(x, e.w, acc[r][3]);
                         }
                     }
                 }
@@ -162,6 +173,7 @@ void vq_tier1_kernel(const float* __restrict__ z, const float* __restrict__ eT, 
 }
 
 // One wave per flagged row; bit recipe of ATen's scalar cdist loop (see oracle/vq_p4.c).
+template <int P>
 __global__ __launch_bounds__(256)
 void vq_tier2_kernel(const float* __restrict__ z, const float* __restrict__ embed, int K, int D,
                      int* __restrict__ idx32, const int* __restrict__ flag_count,
@@ -186,11 +198,11 @@ void vq_tier2_kernel(const float* __restrict__ z, const float* __restrict__ embe
                 for (int j = 0; j < 4; ++j) {
                     const double dd = (double)fabsf(dx[j]);
                     const double q = dd * dd;              // exact (48 bits)
-                    const float t = (float)(q * q);        // RN_f32(d^4)
+                    const float t = (float)(P == 4 ? q * q : (P == 3 ? q * dd : q * q * dd));   // RN_f32(|d|^P)
                     agg = agg + t;                         // sequential fp32 adds, channel order
                 }
             }
-            const float fin = (float)sqrt(sqrt((double)agg));   // RN_f32(agg^(1/4))
+            const float fin = P == 4 ? (float)sqrt(sqrt((double)agg)) : (float)pow((double)agg, 1.0 / P);   // RN_f32(agg^(1/P))
             if (fin < bf) { bf = fin; bi = k; }                 // k ascends per lane
         }
 #pragma unroll
@@ -384,7 +396,7 @@ int vq_filter_run(const float* z, const float* embed, int64_t N, int K, int D, f
 // shared with the fused projected quantiser (vq_proj.hip)
 int vq_tier2_run(const float* z, const float* embed, int K, int D, int* idx32, const int* flag_count, const int* flag_list,
                  hipStream_t stream) {
-    vq_tier2_kernel<<<256, 256, 0, stream>>>(z, embed, K, D, idx32, flag_count, flag_list);
+    vq_tier2_kernel<4><<<256, 256, 0, stream>>>(z, embed, K, D, idx32, flag_count, flag_list);
     VQAE_LAUNCH_CHECK();
     return VQAE_OK;
 }
@@ -441,7 +453,15 @@ extern "C" size_t vqae_vq_workspace_bytes(int64_t n_rows, int n_codes, int dim) 
 extern "C" int vqae_vq_forward_f32(const float* z, const float* embed, int64_t N, int K, int D, float commitment,
                                    void* idx_out, int idx_dtype, float* q, float* loss, float* margin, void* ws,
                                    void* stream_) {
+    return vqae_vq_forward_p_f32(z, embed, N, K, D, 4, commitment, idx_out, idx_dtype, q, loss, margin, ws, stream_);
+}
+
+extern "C" int vqae_vq_forward_p_f32(const float* z, const float* embed, int64_t N, int K, int D, int p_norm, float commitment,
+                                     void* idx_out, int idx_dtype, float* q, float* loss, float* margin, void* ws,
+                                     void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    VQAE_REQUIRE(p_norm >= 3 && p_norm <= 5, VQAE_ERR_UNSUPPORTED,
+                 "vq_forward: p = %d (p = inputs.dim(): 3-D, 4-D and 5-D inputs are implemented)", p_norm);
     VQAE_REQUIRE(N >= 0 && N < (1ll << 31), VQAE_ERR_INVALID, "vq_forward: n_rows %lld out of range", (long long)N);
     VQAE_REQUIRE(N == 0 || (z && embed && idx_out && ws), VQAE_ERR_INVALID, "vq_forward: null pointer");
     VQAE_REQUIRE(K >= 1 && K <= 65536, VQAE_ERR_UNSUPPORTED, "vq_forward: n_codes %d unsupported", K);
@@ -465,7 +485,8 @@ extern "C" int vqae_vq_forward_f32(const float* z, const float* embed, int64_t N
         vq_pad_rows_kernel<<<(unsigned)std::min<int64_t>(vqae::ceil_div(N * Dp, 256), 65536), 256, 0, stream>>>(z, N, D, Dp, zp);
         vq_pad_rows_kernel<<<(unsigned)std::min<int64_t>(vqae::ceil_div((int64_t)K * Dp, 256), 65536), 256, 0, stream>>>(embed, K, D, Dp, ep);
         VQAE_LAUNCH_CHECK();
-        int rc = vqae_vq_forward_f32(zp, ep, N, K, Dp, commitment * ((float)Dp / (float)D), idx_out, idx_dtype, qp, loss, margin, wsp, stream_);
+        int rc = vqae_vq_forward_p_f32(zp, ep, N, K, Dp, p_norm, commitment * ((float)Dp / (float)D), idx_out, idx_dtype, qp, loss, margin, wsp,
+                                       stream_);
         if (rc == VQAE_OK && q) {
             vq_unpad_rows_kernel<<<(unsigned)std::min<int64_t>(vqae::ceil_div(N * D, 256), 65536), 256, 0, stream>>>(qp, N, D, Dp, q);
             if (hipGetLastError() != hipSuccess) rc = vqae::fail(VQAE_ERR_HIP, "vq_forward: unpad launch failed");
@@ -488,15 +509,16 @@ extern "C" int vqae_vq_forward_f32(const float* z, const float* embed, int64_t N
         const int td = D < VQ_TD ? D : VQ_TD;
         const size_t lds_bytes = (size_t)td * VQ_TK * sizeof(float);
         if (!attr_set) {
-            VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)vq_tier1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               VQ_TD * VQ_TK * (int)sizeof(float)));
+            VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)vq_tier1_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, VQ_TD * VQ_TK * (int)sizeof(float)));
+            VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)vq_tier1_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, VQ_TD * VQ_TK * (int)sizeof(float)));
+            VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)vq_tier1_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, VQ_TD * VQ_TK * (int)sizeof(float)));
             attr_set = true;
         }
-        // evaluation-noise bound between tier-1 sums and the reference recipe's sums
-        const float thr = (4.0f * (float)D + 16.0f) * 5.9604645e-8f;
+        // evaluation-noise bound between tier-1 sums and the reference recipe's sums; p = 5 has one more rounded product
+        const float thr = ((float)(p_norm > 4 ? p_norm : 4) * (float)D + 16.0f) * 5.9604645e-8f;
         // wide codebooks: the matrix-pipe filter + exact evaluation of the survivors (vq_filter.hip); it leaves flag_count[1] != 0
         // (and does nothing) when the codebook is outside the f16 range of its coefficients -- then, and only then, tier 1 runs
-        const bool filt = !margin && vqae::vq_filter_supported(K, D);
+        const bool filt = p_norm == 4 && !margin && vqae::vq_filter_supported(K, D);
         if (filt) {
             vqae::ProfScope fprof(vqae::PROF_VQ_TIER1, stream, 3.0 * (double)N * K * D);
             const int frc = vqae::vq_filter_run(z, embed, N, K, D, thr, w.idx32, w.flag_count, w.flag_list, w.ftab, stream);
@@ -506,12 +528,19 @@ extern "C" int vqae_vq_forward_f32(const float* z, const float* embed, int64_t N
         // one workgroup per CU (128 KB LDS tile); persistent over row groups
         const unsigned grid = (unsigned)std::min<int64_t>(vqae::ceil_div(N, VQ_ROWS_PER_BLOCK), 256);
         vqae::ProfScope prof(filt ? vqae::PROF_NONE : vqae::PROF_VQ_TIER1, stream, 3.0 * (double)N * K * D);
-        vq_tier1_kernel<<<grid, VQ_WAVES * 64, lds_bytes, stream>>>(z, w.eT, N, K, Kpad, D, thr, w.idx32, margin,
-                                                                  w.flag_count, w.flag_list, filt ? w.flag_count + 1 : nullptr);
+        if (p_norm == 3)
+            vq_tier1_kernel<3><<<grid, VQ_WAVES * 64, lds_bytes, stream>>>(z, w.eT, N, K, Kpad, D, thr, w.idx32, margin, w.flag_count, w.flag_list, nullptr);
+        else if (p_norm == 5)
+            vq_tier1_kernel<5><<<grid, VQ_WAVES * 64, lds_bytes, stream>>>(z, w.eT, N, K, Kpad, D, thr, w.idx32, margin, w.flag_count, w.flag_list, nullptr);
+        else
+            vq_tier1_kernel<4><<<grid, VQ_WAVES * 64, lds_bytes, stream>>>(z, w.eT, N, K, Kpad, D, thr, w.idx32, margin, w.flag_count, w.flag_list,
+                                                                           filt ? w.flag_count + 1 : nullptr);
         prof.done();
         VQAE_LAUNCH_CHECK();
     }
-    vq_tier2_kernel<<<256, 256, 0, stream>>>(z, embed, K, D, w.idx32, w.flag_count, w.flag_list);
+    if (p_norm == 3) vq_tier2_kernel<3><<<256, 256, 0, stream>>>(z, embed, K, D, w.idx32, w.flag_count, w.flag_list);
+    else if (p_norm == 5) vq_tier2_kernel<5><<<256, 256, 0, stream>>>(z, embed, K, D, w.idx32, w.flag_count, w.flag_list);
+    else vq_tier2_kernel<4><<<256, 256, 0, stream>>>(z, embed, K, D, w.idx32, w.flag_count, w.flag_list);
     VQAE_LAUNCH_CHECK();
 
     if (q || loss) {

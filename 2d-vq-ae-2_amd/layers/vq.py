@@ -73,21 +73,25 @@ class EMAVectorQuantizer(nn.Module):
             raise NotImplementedError(
                 'VQ dim != channel dim not supported;'
                 f' found channel dim of {inputs.shape[1]}, expected {self.embedding_dim}')
-        if ndim != 4:
-            # the reference's distance exponent is p = inputs.dim() (vq.py:121-129); the HIP kernel
-            # implements the 2-D (NCHW, p = 4) case that every shipped config uses
-            raise NotImplementedError(f'only NCHW inputs (p = 4) are implemented; got {ndim}-D input')
+        if ndim > 5:
+            # the reference's distance exponent is p = inputs.dim() (vq.py:121-129); the kernels implement p = 3, 4, 5
+            raise NotImplementedError(f'inputs of rank 3 .. 5 (p = 3, 4, 5) are implemented; got a {ndim}-D input')
         with torch.no_grad():
-            nhwc = ops.nchw_to_nhwc(inputs.detach().float())
-            B, H, W, D = nhwc.shape
-            flat_input = nhwc.reshape(-1, D)
+            x = inputs.detach().float()
+            if ndim == 4:
+                cl = ops.nchw_to_nhwc(x)
+            else:                                                      # channel last (vq.py:107-113): [B, L, D] / [B, d, h, w, D]
+                cl = x.permute(0, *range(2, ndim), 1).contiguous()
+            D = cl.shape[-1]
+            flat_input = cl.reshape(-1, D)
             if self.first_pass and self.training:
                 self._init_ema(flat_input)
-            q_flat, idx, loss, _ = ops.vq_forward(flat_input, self.embed, self.commitment_cost)
+            q_flat, idx, loss, _ = ops.vq_forward(flat_input, self.embed, self.commitment_cost, p=ndim)
             if self.training:
                 self._update_ema(flat_input, idx)
-            quantized = ops.nhwc_to_nchw(q_flat.reshape(B, H, W, D))    # = inputs + (q - inputs), vq.py:146
-            encoding_indices = idx.reshape(B, H, W)
+            q_cl = q_flat.reshape(cl.shape)                             # = inputs + (q - inputs), vq.py:146
+            quantized = ops.nhwc_to_nchw(q_cl) if ndim == 4 else q_cl.permute(0, -1, *range(1, ndim - 1)).contiguous()
+            encoding_indices = idx.reshape(cl.shape[:-1])
         return quantized, encoding_indices, loss
 
 

@@ -182,8 +182,9 @@ def bicubic_up2(x, pre_bias=0.0):
     return y
 
 
-def vq_forward(z_flat, embed, commitment_cost=1.0, idx_dtype=torch.int64, want_q=True, want_margin=False):
-    """z_flat [N, D], embed [K, D] -> (q [N, D] | None, idx [N], loss 0-d, margin [N] | None)."""
+def vq_forward(z_flat, embed, commitment_cost=1.0, idx_dtype=torch.int64, want_q=True, want_margin=False, p=4):
+    """z_flat [N, D], embed [K, D] -> (q [N, D] | None, idx [N], loss 0-d, margin [N] | None).  p: the Minkowski exponent of the
+    reference's cdist = the rank of the quantiser's input (vq.py:97,121-129): 4 for NCHW, 3 / 5 for [B, D, L] / [B, D, d, h, w]."""
     _need_gpu(z_flat, embed)
     z_flat = z_flat.contiguous()
     embed = embed.contiguous()
@@ -195,8 +196,8 @@ def vq_forward(z_flat, embed, commitment_cost=1.0, idx_dtype=torch.int64, want_q
     loss = torch.zeros((), dtype=torch.float32, device=dev)
     margin = torch.empty(N, dtype=torch.float32, device=dev) if want_margin else None
     ws = torch.empty(L.lib().vqae_vq_workspace_bytes(N, K, D), dtype=torch.uint8, device=dev)
-    L.check(L.lib().vqae_vq_forward_f32(_p(z_flat), _p(embed), N, K, D, float(commitment_cost), _p(idx),
-                                        idx_code(idx_dtype), _p(q), _p(loss), _p(margin), _p(ws), _stream()))
+    L.check(L.lib().vqae_vq_forward_p_f32(_p(z_flat), _p(embed), N, K, D, int(p), float(commitment_cost), _p(idx),
+                                          idx_code(idx_dtype), _p(q), _p(loss), _p(margin), _p(ws), _stream()))
     return q, idx, loss, margin
 
 

@@ -76,6 +76,15 @@ int vqae_vq_forward_f32(const float* z_dev, const float* embed_dev, int64_t n_ro
                         float commitment_cost, void* idx_dev, int idx_dtype, float* q_dev, float* loss_dev,
                         float* margin_dev, void* workspace_dev, void* stream);
 
+/* The same with the Minkowski exponent spelled out: the reference passes `p = inputs.dim()` to torch.cdist (vq.py:97,121-129), i.e.
+ * p = 3 for [B, D, L] inputs, 4 for [B, D, h, w] (vqae_vq_forward_f32), 5 for [B, D, d, h, w]:
+ *   idx[n] = argmin_k ( sum_c |z[n][c] - embed[k][c]|^p )^(1/p), lowest k on ties.
+ * z_dev is the channel-last flattening of the input (vq.py:107-116) whatever its rank.
+ * Errors: p outside 3 .. 5 -> VQAE_ERR_UNSUPPORTED; otherwise as vqae_vq_forward_f32. */
+int vqae_vq_forward_p_f32(const float* z_dev, const float* embed_dev, int64_t n_rows, int n_codes, int dim, int p,
+                          float commitment_cost, void* idx_dev, int idx_dtype, float* q_dev, float* loss_dev,
+                          float* margin_dev, void* workspace_dev, void* stream);
+
 /* ProjectedEMAVectorQuantizer2d.forward (vq.py:190-192), projection_dim = 8 (the reference default,
  * conf/model/layers/vq/projected_ema_vq_2d.yaml): proj_out(VQ(proj_in(x))) in one pass over the activation.
  *   x_dev      [n_rows][channels] fp32 (NHWC activation)

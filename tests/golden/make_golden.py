@@ -7,7 +7,7 @@ Runs only in the build container (the reference does not exist on the GPU box). 
 data: inputs are regenerated from seeds by oracle.vqae_oracle.make_* on both sides; the files hold
 the reference's outputs (indices, losses, samples of activations), never reference source.
 
-    python tests/golden/make_golden.py [--only vq,tiny,B,A,C,driver,ema]
+    python tests/golden/make_golden.py [--only vq,vqnd,tiny,B,A,C,driver,ema]
 """
 import argparse
 import os
@@ -69,6 +69,35 @@ def gen_vq():
         save(f"vq_D{D}_K{K}", D=D, K=K, N=N, seed=0, idx=idx.reshape(-1).numpy().astype(np.uint16),
              loss=np.float32(loss.item()), q_flat_sample=q.permute(0, 2, 3, 1).reshape(N, D)[::61].numpy(),
              best=best.numpy(), second=second.numpy(), cdist_bitwise_match=np.float64(match))
+
+
+def gen_vq_nd():
+    """EMAVectorQuantizer.forward on 3-D and 5-D inputs: the reference passes p = inputs.dim() to torch.cdist (vq.py:97,121-129),
+    so [B, D, L] is quantised under the 3-norm and [B, D, d, h, w] under the 5-norm.  Adversarial rows as in the 4-D cases."""
+    S.install()
+    from vq_ae.layers.vq import EMAVectorQuantizer  # the reference
+    import ctypes
+    for tag, D, K, shape in (("3d", 16, 64, (4, 256)), ("5d", 12, 40, (2, 4, 8, 16)), ("3d_wide", 128, 256, (2, 512))):
+        N = int(np.prod(shape))
+        nd = len(shape) + 1
+        z, embed = O.make_vq_case(D, K, N, seed=3)
+        vq = EMAVectorQuantizer(num_embeddings=K, embedding_dim=D, commitment_cost=1.0, decay=0.99, laplace_alpha=1e-5).eval()
+        vq.embed.copy_(embed)
+        zin = z.reshape(*shape, D).permute(0, -1, *range(1, len(shape))).contiguous()      # [B, D, *spatial]
+        assert zin.dim() == nd
+        q, idx, loss = vq(zin)
+        dist = torch.cdist(z, embed, float(nd), compute_mode="donot_use_mm_for_euclid_dist")
+        mine = torch.empty_like(dist)
+        O._c_lib().vq_p4_cdist_ref(z.data_ptr(), embed.data_ptr(), N, K, D, ctypes.c_float(float(nd)), mine.data_ptr(), os.cpu_count())
+        match = (mine == dist).float().mean().item()
+        oq, oi, ol = O.vq_forward(zin, embed, 1.0)
+        assert torch.equal(oi, idx), "oracle argmin != reference"
+        assert torch.equal(oq, q) and float(ol) == float(loss)
+        oidx, best, second = O.vq_argmin_p4(z, embed, float(nd))
+        print(f"  vq {tag}: rank-{nd} input {tuple(zin.shape)} (p = {nd}), C-oracle cdist bitwise match {match * 100:.4f}%, argmin equal, "
+              f"min margin {(second - best).min().item():.3e}")
+        save(f"vq_nd_{tag}", D=D, K=K, N=N, seed=3, shape=np.asarray(shape), idx=idx.reshape(-1).numpy().astype(np.uint16),
+             loss=np.float32(loss.item()), q_sample=q.reshape(q.shape[0], D, -1)[:, :, ::7].numpy(), cdist_bitwise_match=np.float64(match))
 
 
 # ---------------------------------------------------------------- G2..G4: model cases
@@ -323,12 +352,14 @@ def gen_ema():
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="vq,tiny,tinyP,B,A,C,driver,ema,autocast,mbconv,taps")
+    ap.add_argument("--only", default="vq,vqnd,tiny,tinyP,B,A,C,driver,ema,autocast,mbconv,taps")
     args = ap.parse_args()
     todo = args.only.split(",")
     torch.manual_seed(0)
     if "vq" in todo:
         print("G1 vq"); gen_vq()
+    if "vqnd" in todo:
+        print("G1b vq on 3-D / 5-D inputs"); gen_vq_nd()
     if "tiny" in todo:
         print("G2 tiny"); gen_model("tiny", 2, 32, True)
     if "tinyP" in todo:

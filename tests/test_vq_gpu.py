@@ -61,6 +61,48 @@ def test_vq_any_embedding_dim(amd, oracle, N, D, K):
     assert torch.equal(got, embed[oidx])
 
 
+@pytest.mark.parametrize("tag", ["3d", "5d", "3d_wide"])
+def test_vq_on_3d_and_5d_inputs(amd, oracle, tag):
+    """p = inputs.dim() (vq.py:97,121-129): the kernel under the 3- / 5-norm and the module mirror on [B, D, L] / [B, D, d, h, w]
+    inputs against the fixture recorded from the reference (indices bit-exact incl. the duplicate-code / near-tie rows, q bit-exact
+    on the sample, loss <= 1e-6 relative)."""
+    from vqae_amd.layers.vq import EMAVectorQuantizer
+    g = load_golden(f"vq_nd_{tag}")
+    D, K, N = int(g["D"]), int(g["K"]), int(g["N"])
+    shape = tuple(int(v) for v in g["shape"])
+    nd = len(shape) + 1
+    z, embed = oracle.make_vq_case(D, K, N, seed=int(g["seed"]))
+    ref = g["idx"].astype(np.int64)
+    q, idx, loss, margin = amd.ops.vq_forward(z.cuda(), embed.cuda(), 1.0, want_margin=True, p=nd)
+    assert np.array_equal(idx.cpu().numpy(), ref), f"{(idx.cpu().numpy() != ref).sum()} index mismatches (p = {nd})"
+    assert torch.equal(q.cpu(), z + (embed[idx.cpu()] - z))
+    assert abs(float(loss) - float(g["loss"])) <= 1e-6 * abs(float(g["loss"]))
+    assert idx[:4].tolist() == [0, 1, 2, 3] and bool(torch.all(margin[:4].cpu() == 0))      # adversarial duplicates -> lowest index
+    m = EMAVectorQuantizer(K, D, 1.0, 0.99, 1e-5).eval()
+    with torch.no_grad():
+        m.embed.copy_(embed)
+    m = m.cuda()
+    zin = z.reshape(*shape, D).permute(0, -1, *range(1, len(shape))).contiguous()
+    qm, im, lm = m(zin.cuda())
+    assert qm.shape == zin.shape and im.shape == shape and im.dtype == torch.int64
+    assert np.array_equal(im.reshape(-1).cpu().numpy(), ref)
+    assert np.array_equal(qm.reshape(qm.shape[0], D, -1)[:, :, ::7].cpu().numpy(), g["q_sample"])
+    assert abs(float(lm) - float(g["loss"])) <= 1e-6 * abs(float(g["loss"]))
+
+
+def test_vq_input_rank_errors(amd):
+    """Reference error behaviour: AssertionError for ndim < 3 (vq.py:98), NotImplementedError for a wrong channel count
+    (vq.py:100-104); ranks above 5 (p > 5) are not implemented here."""
+    from vqae_amd.layers.vq import EMAVectorQuantizer
+    m = EMAVectorQuantizer(8, 4, 1.0, 0.99, 1e-5).eval().cuda()
+    with pytest.raises(AssertionError):
+        m(torch.zeros(3, 4).cuda())
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(2, 5, 7).cuda())
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(1, 4, 2, 2, 2, 2).cuda())
+
+
 def test_vq_empty(amd):
     q, idx, loss, _ = amd.ops.vq_forward(torch.zeros(0, 8).cuda(), torch.randn(4, 8).cuda(), want_margin=True)
     torch.cuda.synchronize()

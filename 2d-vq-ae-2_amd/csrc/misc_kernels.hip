@@ -187,14 +187,24 @@ template <int CB, int CO>
 __global__ __launch_bounds__(256)
 void up_tail_kernel(const float4* __restrict__ q, const float4* __restrict__ sk, const float* __restrict__ w3, int B, int H,
                     int W, int tiles_x, int tiles_y, float b3a, float b3b, float scale, float b4, float* __restrict__ y) {
-    constexpr int LB = CB + 4, LS = CO + 4, GB = CB / 4, GS = CO / 4, NG = GB + GS, HC = CO / 2;
+    constexpr int LB = CB + 4, LS = CO + 4, GB = CB / 4, GS = CO / 4, NG = GB + GS;
+    constexpr int NTL = (CO + 15) / 16;                                             // 16-channel output tiles (CO = 8: half a tile)
+    static_assert(CB % 16 == 0 && CO % 4 == 0, "conv3 runs on 16x16x4 MFMA tiles");
     const float w75[4] = {-0.03515625f, 0.26171875f, 0.87890625f, -0.10546875f};   // even outputs (offset .75)
     const float w25[4] = {-0.10546875f, 0.87890625f, 0.26171875f, -0.03515625f};   // odd outputs  (offset .25)
     __shared__ __attribute__((aligned(16))) float Tb[128 * LB];                     // ELU'd resized branch [pixel][ci]
     __shared__ __attribute__((aligned(16))) float Ts[128 * LS];                     // resized skip [pixel][co]
-    __shared__ __attribute__((aligned(16))) float Wl[CB * CO];                      // conv3 weights [ci][co]
     const int tid = threadIdx.x;
-    for (int i = tid; i < CB * CO; i += 256) Wl[i] = w3[(i % CO) * CB + i / CO];   // packed rows are [co][ci]
+    // conv3 weights as the MFMA row operand, kept in registers for the whole (persistent) launch: lane (li, q) of n-tile nt, k-slice s
+    // holds w3[co = 16 nt + li][ci = 16 s + 4 q .. + 3] (packed rows are [co][ci])
+    float4 w3r[NTL][CB / 16];
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+        for (int s_ = 0; s_ < CB / 16; ++s_) {
+            const int co = 16 * nt + (tid & 15);
+            w3r[nt][s_] = co < CO ? *reinterpret_cast<const float4*>(w3 + co * CB + 16 * s_ + 4 * ((tid & 63) >> 4)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     const int OW = 2 * W, OH = 2 * H;
     const int n_tiles = B * tiles_x * tiles_y;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -202,7 +212,7 @@ void up_tail_kernel(const float4* __restrict__ q, const float4* __restrict__ sk,
         const int tyi = (tile / tiles_x) % tiles_y;
         const int64_t b = tile / (tiles_x * tiles_y);
         const int bi0 = 2 * tyi - 1, bj0 = 16 * txi - 1;                            // first resize block of the tile
-        __syncthreads();                                                           // previous tile's phase 2 is done (and Wl is written)
+        __syncthreads();                                                           // previous tile's phase 2 is done
         // ---- phase 1 ------------------------------------------------------------------------------------------------
         for (int it = tid; it < 32 * NG; it += 256) {
             const int g = it % NG, blk = it / NG;
@@ -258,37 +268,43 @@ void up_tail_kernel(const float4* __restrict__ q, const float4* __restrict__ sk,
             }
         }
         __syncthreads();
-        // ---- phase 2 ------------------------------------------------------------------------------------------------
+        // ---- phase 2: conv3 on the fp32 MFMA (round 3; it was CB x CO / 2 broadcast FMAs per thread) ------------------------------------
+        // v_mfma_f32_16x16x4_f32 with the weights as the row operand: lane (li, q) feeds Tb[pixel li][16 s + 4 q ..] and receives
+        // D[4 q + r][li] = 4 consecutive output channels of its pixel -> 16-byte skip read and store.  A wave owns 2 groups of 16 pixels.
         {
-            const int px = tid & 127, half = tid >> 7;                               // half is wave-uniform
-            const int oy = 2 * bi0 + 1 + (px >> 5), ox = 2 * bj0 + 1 + (px & 31);
-            float acc[HC];
+            const int lane = tid & 63, wv = tid >> 6;
+            const int li = lane & 15, q = lane >> 4;
 #pragma unroll
-            for (int co = 0; co < HC; ++co) acc[co] = 0.f;
+            for (int gg = 0; gg < 2; ++gg) {
+                const int px = 32 * wv + 16 * gg + li;
+                const int oy = 2 * bi0 + 1 + (px >> 5), ox = 2 * bj0 + 1 + (px & 31);
+                float4 tb[CB / 16];
 #pragma unroll
-            for (int c4 = 0; c4 < GB; ++c4) {
-                const float4 t = *reinterpret_cast<const float4*>(Tb + px * LB + 4 * c4);
-                const float tv[4] = {t.x, t.y, t.z, t.w};
+                for (int s_ = 0; s_ < CB / 16; ++s_) tb[s_] = *reinterpret_cast<const float4*>(Tb + px * LB + 16 * s_ + 4 * q);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float* wr = Wl + (4 * c4 + e) * CO + HC * half;
+                for (int nt = 0; nt < NTL; ++nt) {
+                    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+                    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int co = 0; co < HC; ++co) acc[co] = __builtin_fmaf(tv[e], wr[co], acc[co]);
-                }
-            }
-            if (oy >= 0 && oy < OH && ox >= 0 && ox < OW) {
-                float* dst = y + ((b * OH + oy) * OW + ox) * CO + HC * half;
-                const float* sp = Ts + px * LS + HC * half;
-#pragma unroll
-                for (int g = 0; g < HC / 4; ++g) {
-                    float o[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float tv = acc[4 * g + e] * scale;
-                        tv = tv + b4;
-                        o[e] = tv + sp[4 * g + e];
+                    for (int s_ = 0; s_ < CB / 16; ++s_) {
+                        const float4 wv4 = w3r[nt][s_];
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv4.x, tb[s_].x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv4.y, tb[s_].y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv4.z, tb[s_].z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv4.w, tb[s_].w, acc, 0, 0, 0);
                     }
-                    *reinterpret_cast<float4*>(dst + 4 * g) = make_float4(o[0], o[1], o[2], o[3]);
+                    if (oy >= 0 && oy < OH && ox >= 0 && ox < OW && 16 * nt + 4 * q < CO) {
+                        const float4 sp = *reinterpret_cast<const float4*>(Ts + px * LS + 16 * nt + 4 * q);
+                        float o[4];
+                        const float sv[4] = {sp.x, sp.y, sp.z, sp.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float tv = acc[e] * scale;
+                            tv = tv + b4;
+                            o[e] = tv + sv[e];
+                        }
+                        *reinterpret_cast<float4*>(y + ((b * OH + oy) * OW + ox) * CO + 16 * nt + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
+                    }
                 }
             }
         }

@@ -361,6 +361,76 @@ void stitch_kernel(const TI* __restrict__ tiles, const int32_t* __restrict__ rc,
     if (gy < gh && gx < gw) grid[gy * gw + gx] = (TO)tiles[i];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Register-blocked fp32 out_stem (round 3).  The one-thread-per-pixel kernel above issues one LDS weight read per 3 FMAs and 36
+// global loads per pixel at C -> 3: 0.65 ms at cfg B where the bytes need 0.2 ms.
+//   ostem_rb_kernel<CIN>:  CIN / 4 lanes share a pixel, each with 4 input channels and ITS 9 x 4 x 3 weights in registers for the
+//     whole (grid-stride) launch; 9 16-byte loads and 108 FMAs per pixel and lane, a butterfly over the lanes of the pixel, one
+//     lane adds the bias and stores the 3 outputs.  (Partial sums per channel quad: a summation order of its own, fp32 rounding.)
+//     0.65 -> 0.57 ms.  The same idea for in_stem (a thread = 4 pixels x 4 output channels, weights from LDS once per 16 FMAs)
+//     measured SLOWER than the kernel above (0.61 vs 0.54 ms: twice the global load instructions per pixel) and is not kept.
+// Same zero padding and bias as conv3x3_direct_kernel; fp32 only (the 16-bit modes have stem16.hip).
+// ------------------------------------------------------------------------------------------------
+template <int CIN>
+__global__ __launch_bounds__(256)
+void ostem_rb_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, int B, int H, int W,
+                     float* __restrict__ y, int y_nchw) {
+    constexpr int QN = CIN / 4;                                                     // lanes per pixel (a power of two <= 16)
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    const int q = threadIdx.x % QN;
+    f32x4_t wr[9][3];                                                               // [tap][co] over this lane's 4 input channels
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int co = 0; co < 3; ++co)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wr[tap][co][e] = w[((int64_t)co * CIN + 4 * q + e) * 9 + tap];
+    const float b0 = bias[0], b1 = bias[1], b2 = bias[2];
+    const int hw = H * W;
+    const int64_t npix = (int64_t)B * hw;
+    const int64_t stride = (int64_t)gridDim.x * (256 / QN);
+    // every lane of the wave runs the same number of trips (the butterfly needs all of a pixel's lanes): clamp, store masked
+    const int64_t trips = (npix + stride - 1) / stride;
+    int64_t pix = (int64_t)blockIdx.x * (256 / QN) + threadIdx.x / QN;
+    for (int64_t t = 0; t < trips; ++t, pix += stride) {
+        const bool live = pix < npix;
+        const int64_t pc = live ? pix : npix - 1;
+        const int b = (int)(pc / hw), rem = (int)(pc - (int64_t)b * hw);
+        const int oy = rem / W, ox = rem - oy * W;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+            const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const int64_t src = ((int64_t)b * hw + (ok ? (int64_t)iy * W + ix : rem)) * CIN + 4 * q;
+            f32x4_t v = *reinterpret_cast<const f32x4_t*>(x + src);
+            if (!ok) v = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a0 = __builtin_fmaf(v[e], wr[tap][0][e], a0);
+                a1 = __builtin_fmaf(v[e], wr[tap][1][e], a1);
+                a2 = __builtin_fmaf(v[e], wr[tap][2][e], a2);
+            }
+        }
+#pragma unroll
+        for (int off = 1; off < QN; off <<= 1) {
+            a0 += __shfl_xor(a0, off);
+            a1 += __shfl_xor(a1, off);
+            a2 += __shfl_xor(a2, off);
+        }
+        if (live && q == 0) {
+            a0 += b0; a1 += b1; a2 += b2;
+            if (y_nchw) {
+                y[((int64_t)b * 3 + 0) * hw + rem] = a0;
+                y[((int64_t)b * 3 + 1) * hw + rem] = a1;
+                y[((int64_t)b * 3 + 2) * hw + rem] = a2;
+            } else {
+                y[pix * 3 + 0] = a0; y[pix * 3 + 1] = a1; y[pix * 3 + 2] = a2;
+            }
+        }
+    }
+}
+
 template <int CIN, int COUT>
 int launch_direct(const void* x, int x_kind, const Norm3& nrm, const float* w, const float* bias, int B, int H, int W,
                   float* y, int y_nchw, int dt, hipStream_t stream) {
@@ -528,6 +598,18 @@ int conv3x3_direct(const void* x, int x_kind, const float* mean255, const float*
     VQAE_REQUIRE(x && w && bias && y, VQAE_ERR_INVALID, "conv3x3_direct: null pointer");
     VQAE_REQUIRE(x_kind != 2 || cin == 3, VQAE_ERR_UNSUPPORTED, "conv3x3_direct: uint8 input needs cin == 3");
     if ((int64_t)B * H * W == 0) return VQAE_OK;
+    static const bool no_rb = getenv("VQAE_NO_STEM_RB") && atoi(getenv("VQAE_NO_STEM_RB"));
+    if (!no_rb && dt == VQAE_DT_F32) {                                      // register-blocked fp32 stems
+        if (cout == 3 && x_kind == 0 && (cin == 8 || cin == 16 || cin == 32)) {
+            const int64_t npix = (int64_t)B * H * W;
+            const unsigned grid = (unsigned)std::min<int64_t>(vqae::ceil_div(npix, 256 / (cin / 4)), 256 * 12);
+            if (cin == 8) ostem_rb_kernel<8><<<grid, 256, 0, stream>>>((const float*)x, w, bias, B, H, W, y, y_nchw);
+            else if (cin == 16) ostem_rb_kernel<16><<<grid, 256, 0, stream>>>((const float*)x, w, bias, B, H, W, y, y_nchw);
+            else ostem_rb_kernel<32><<<grid, 256, 0, stream>>>((const float*)x, w, bias, B, H, W, y, y_nchw);
+            VQAE_LAUNCH_CHECK();
+            return VQAE_OK;
+        }
+    }
 #define VQAE_DIRECT_CASE(CI, CO) \
     if (cin == CI && cout == CO) return launch_direct<CI, CO>(x, x_kind, nrm, w, bias, B, H, W, y, y_nchw, dt, stream);
     VQAE_DIRECT_CASE(3, 4) VQAE_DIRECT_CASE(3, 8) VQAE_DIRECT_CASE(3, 16) VQAE_DIRECT_CASE(3, 32) VQAE_DIRECT_CASE(3, 64)

@@ -378,9 +378,10 @@ static int vqf_kp(int K) { return (int)round_up(K, 128); }
 
 bool vq_filter_supported(int K, int D) {
     static const bool off = getenv("VQAE_NO_VQ_FILTER") && atoi(getenv("VQAE_NO_VQ_FILTER"));
-    // measured (N = 262 144): D = 256, K = 1024: 4.14 -> 1.86 ms; D = 128, K = 256: 0.52 -> 0.48 ms (operand build + the serial
-    // phases of one 4-wave workgroup per CU eat the gain): the filter takes the wide codebooks only
-    return !off && D == 256 && K >= 32 && K <= 32768;
+    // measured (N = 262 144): D = 256, K = 1024: 4.14 -> 1.86 ms; D = 128, K = 256 with 128-row tiles (one 4-wave workgroup per CU):
+    // 0.52 -> 0.48 ms; round 3, 64-row tiles (two workgroups per CU): 0.60 -> 0.46 ms on N(0, 1) data: taken for 128 channels too
+    static const bool no128 = getenv("VQAE_NO_VQ_FILTER_128") && atoi(getenv("VQAE_NO_VQ_FILTER_128"));
+    return !off && (D == 256 || (D == 128 && !no128)) && K >= 32 && K <= 32768;
 }
 
 size_t vq_filter_table_bytes(int K, int D) { return (size_t)vqf_kp(K) * (3 * D + 16) * 2; }
@@ -401,6 +402,7 @@ int vq_filter_run(const float* z, const float* embed, int64_t N, int K, int D, f
     k.idx32 = idx32; k.flags = flags; k.flag_list = flag_list;
     const int rt = 64;
     k.n_tiles = (int)ceil_div(N, rt);
+    if (D == 128) return launch_vqf<128, 64>(k, stream);
     return launch_vqf<256, 64>(k, stream);
 }
 

@@ -445,7 +445,7 @@ __global__ void vq_unpad_rows_kernel(const float* __restrict__ src, int64_t n, i
 
 extern "C" size_t vqae_vq_workspace_bytes(int64_t n_rows, int n_codes, int dim) {
     const int64_t Kpad = vqae::round_up(n_codes, VQ_TK);
-    const size_t ftab = (dim == 256) ? (size_t)vqae::round_up((int64_t)vqae::vq_filter_table_bytes(n_codes, dim), 256) : 0;
+    const size_t ftab = (dim == 256 || dim == 128) ? (size_t)vqae::round_up((int64_t)vqae::vq_filter_table_bytes(n_codes, dim), 256) : 0;
     return (size_t)(256 + 1024 * sizeof(double) + vqae::round_up((int64_t)dim * Kpad * 4, 256) +
                     2 * vqae::round_up(n_rows * 4, 256) + 256) + ftab;
 }

@@ -292,7 +292,7 @@ def run_leg(args, ctx, headline):
                                    "valu_frac_of_78.6Tops": round(alg / (avg_ms * 1e-3) / 78.6e12, 4)}
             else:                          # VQ tier 1: algorithmic HBM bytes = N*D*4 read + N*4 idx; VALU-bound
                 byts = M * spec.code_dim * 4.0 + M * 4.0
-                res["roofline"] = {"kernel": "vq_tier1_kernel", "bound": "hbm",
+                res["roofline"] = {"kernel": "plain p=4 lookup: vqf_main_kernel (f16 MFMA filter + exact survivors) at 128 / 256 channels, else vq_tier1_kernel", "bound": "hbm",
                                    "achieved": round(byts / (avg_ms * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS,
                                    "unit": "GB/s", "traffic": None, "launches": k_n.value,
                                    "avg_ms": round(avg_ms, 4), "alg_bytes_per_launch": byts,

@@ -233,14 +233,17 @@ void up_tail_kernel(const float4* __restrict__ q, const float4* __restrict__ sk,
                 float4 v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = row[(int64_t)xs[j] * C4];
+                // accumulation steps as fmas (round 3): the resize is this kernel's vector-issue bound (PMC: 401 M vector instructions per
+                // launch against 9.6 M MFMAs) and a * b + c written as two instructions was a third of them; <= 1 fp32 ulp per tap from
+                // the unfused form (the fp32 handle's conv-before-resize order is not bit-comparable with the reference's anyway)
                 ho[r].x = v[0].x * w25[0]; ho[r].y = v[0].y * w25[0]; ho[r].z = v[0].z * w25[0]; ho[r].w = v[0].w * w25[0];
                 he[r].x = v[0].x * w75[0]; he[r].y = v[0].y * w75[0]; he[r].z = v[0].z * w75[0]; he[r].w = v[0].w * w75[0];
 #pragma unroll
                 for (int j = 1; j < 4; ++j) {
-                    ho[r].x = ho[r].x + v[j].x * w25[j]; ho[r].y = ho[r].y + v[j].y * w25[j];
-                    ho[r].z = ho[r].z + v[j].z * w25[j]; ho[r].w = ho[r].w + v[j].w * w25[j];
-                    he[r].x = he[r].x + v[j].x * w75[j]; he[r].y = he[r].y + v[j].y * w75[j];
-                    he[r].z = he[r].z + v[j].z * w75[j]; he[r].w = he[r].w + v[j].w * w75[j];
+                    ho[r].x = __builtin_fmaf(v[j].x, w25[j], ho[r].x); ho[r].y = __builtin_fmaf(v[j].y, w25[j], ho[r].y);
+                    ho[r].z = __builtin_fmaf(v[j].z, w25[j], ho[r].z); ho[r].w = __builtin_fmaf(v[j].w, w25[j], ho[r].w);
+                    he[r].x = __builtin_fmaf(v[j].x, w75[j], he[r].x); he[r].y = __builtin_fmaf(v[j].y, w75[j], he[r].y);
+                    he[r].z = __builtin_fmaf(v[j].z, w75[j], he[r].z); he[r].w = __builtin_fmaf(v[j].w, w75[j], he[r].w);
                 }
             }
 #pragma unroll
@@ -253,8 +256,8 @@ void up_tail_kernel(const float4* __restrict__ q, const float4* __restrict__ sk,
                     o.x = in[0].x * wy[0]; o.y = in[0].y * wy[0]; o.z = in[0].z * wy[0]; o.w = in[0].w * wy[0];
 #pragma unroll
                     for (int r = 1; r < 4; ++r) {
-                        o.x = o.x + in[r].x * wy[r]; o.y = o.y + in[r].y * wy[r];
-                        o.z = o.z + in[r].z * wy[r]; o.w = o.w + in[r].w * wy[r];
+                        o.x = __builtin_fmaf(in[r].x, wy[r], o.x); o.y = __builtin_fmaf(in[r].y, wy[r], o.y);
+                        o.z = __builtin_fmaf(in[r].z, wy[r], o.z); o.w = __builtin_fmaf(in[r].w, wy[r], o.w);
                     }
                     const int px = (2 * (blk >> 4) + a) * 32 + 2 * (blk & 15) + c;   // pixel of the 4 x 32 tile
                     if (branch) {

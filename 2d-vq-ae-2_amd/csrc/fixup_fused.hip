@@ -419,7 +419,7 @@ int launch_tiny_r(FusedP& p, hipStream_t stream) {
 //     layout conv3's B operand wants, runs conv3 per sub-pixel, adds the residual and stores 16 bytes per pixel.
 // No LDS traffic and no barrier between conv1 and the store; U = G g G^T (16 x [16 x 16], 16 KiB) is built once per
 // (persistent) workgroup and read as linear 1 KiB fragments.  Results differ from the direct form by fp32 rounding only.
-template <int TH>
+template <int TH, bool PF>
 __global__ __launch_bounds__(256, 3)
 void fixup_same_wino16_kernel(const FusedP p) {
     constexpr int C = 16;
@@ -479,6 +479,25 @@ void fixup_same_wino16_kernel(const FusedP p) {
     const float* const uf = Us + li * 16 + 4 * q;       // + pos * 256: one linear KiB per wave-wide read
     const float* const dp = T1 + ((2 * wave) * 34 + 2 * li) * LDT + 4 * q;   // this lane's 4 x 4 patch: + (i * 34 + j) * LDT
 
+    f32x4 xin[GPW];
+    auto p1_load = [&](int tile_, f32x4 (&dst)[GPW]) {
+        const int txi_ = tile_ % p.tiles_x;
+        const int tyi_ = (tile_ / p.tiles_x) % p.tiles_y;
+        const int b_ = tile_ / (p.tiles_x * p.tiles_y);
+        const float* const xim_ = p.x + (int64_t)b_ * p.H * p.W * C;
+#pragma unroll
+        for (int gi = 0; gi < GPW; ++gi) {
+            int g = wave + 4 * gi;
+            g = g < G1 ? g : G1 - 1;
+            int hp = 16 * g + li;
+            hp = hp < HP ? hp : HP - 1;
+            const int hy = hp / 34, hx = hp - 34 * hy;
+            int iy = tyi_ * TH + hy - 1, ix = txi_ * 32 + hx - 1;
+            iy = iy < 0 ? iy + p.H : (iy >= p.H ? iy - p.H : iy);
+            ix = ix < 0 ? ix + p.W : (ix >= p.W ? ix - p.W : ix);
+            dst[gi] = *reinterpret_cast<const f32x4*>(xim_ + ((int64_t)iy * p.W + ix) * C + 4 * q);
+        }
+    };
     for (int t = slot; t < xcd_n; t += per_xcd_wg) {
         const int tile = xcd_lo + t;
         const int txi = tile % p.tiles_x;
@@ -488,18 +507,13 @@ void fixup_same_wino16_kernel(const FusedP p) {
         const float* const xim = p.x + (int64_t)b * p.H * p.W * C;
 
         // ---- P1: t1 = ELU(conv1(ELU(x + b1a) + b1b) + b2a) + b2b on the (TH + 2) x 34 halo -> LDS --------------------------------
+        // PF: the halo rows were requested during the previous tile's conv2 / conv3 (xin); else they are requested here
+        if (!PF || t == slot) p1_load(tile, xin);
 #pragma unroll
         for (int gi = 0; gi < GPW; ++gi) {
             const int g = wave + 4 * gi;
             if (g < G1) {
-                int hp = 16 * g + li;
-                hp = hp < HP ? hp : HP - 1;
-                const int hy = hp / 34, hx = hp - 34 * hy;
-                int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
-                iy = iy < 0 ? iy + p.H : (iy >= p.H ? iy - p.H : iy);
-                ix = ix < 0 ? ix + p.W : (ix >= p.W ? ix - p.W : ix);
-                f32x4 v = *reinterpret_cast<const f32x4*>(xim + ((int64_t)iy * p.W + ix) * C + 4 * q);
-                v = v + p.b1a;
+                f32x4 v = xin[gi] + p.b1a;
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -530,6 +544,7 @@ void fixup_same_wino16_kernel(const FusedP p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) d[i][j] = *reinterpret_cast<const f32x4*>(dp + (i * 34 + j) * LDT);
         __syncthreads();                                // every wave holds its patches: the next tile's conv1 may overwrite t1
+        if (PF && t + per_xcd_wg < xcd_n) p1_load(xcd_lo + t + per_xcd_wg, xin);   // in flight under conv2 / conv3 of this tile
         f32x4 y00 = {0.f, 0.f, 0.f, 0.f}, y01 = y00, y10 = y00, y11 = y00;
 #pragma unroll
         for (int xi = 0; xi < 4; ++xi) {
@@ -588,15 +603,19 @@ int launch_wino16(FusedP& p, hipStream_t stream) {
     constexpr int lds_bytes = (2 * 16 * K::LDT + 16 * 256 + K::HP * K::LDT) * (int)sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)fixup_same_wino16_kernel<TH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)fixup_same_wino16_kernel<TH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)fixup_same_wino16_kernel<TH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         attr_set = true;
     }
     p.tiles_x = p.W / 32;
     p.tiles_y = p.H / TH;
     p.n_tiles = p.B * p.tiles_x * p.tiles_y;
+    // the next tile's halo rows are requested under this tile's conv2 / conv3 (24 registers): 0.88 -> 0.82 ms; VQAE_WINO16_NO_PF=1: without
+    static const bool pf = !(getenv("VQAE_WINO16_NO_PF") && atoi(getenv("VQAE_WINO16_NO_PF")));
     int grid = 256 * 3;
     if (grid > p.n_tiles) grid = p.n_tiles;
-    fixup_same_wino16_kernel<TH><<<grid, 256, lds_bytes, stream>>>(p);
+    if (pf) fixup_same_wino16_kernel<TH, true><<<grid, 256, lds_bytes, stream>>>(p);
+    else fixup_same_wino16_kernel<TH, false><<<grid, 256, lds_bytes, stream>>>(p);
     VQAE_LAUNCH_CHECK();
     return VQAE_OK;
 }

@@ -504,7 +504,6 @@ void fixup_same_wino16_kernel(const FusedP p) {
         const int tyi = (tile / p.tiles_x) % p.tiles_y;
         const int b = tile / (p.tiles_x * p.tiles_y);
         const int ty0 = tyi * TH, tx0 = txi * 32;
-        const float* const xim = p.x + (int64_t)b * p.H * p.W * C;
 
         // ---- P1: t1 = ELU(conv1(ELU(x + b1a) + b1b) + b2a) + b2b on the (TH + 2) x 34 halo -> LDS --------------------------------
         // PF: the halo rows were requested during the previous tile's conv2 / conv3 (xin); else they are requested here

@@ -51,19 +51,20 @@ def test_autocast_forward_matches_reference_fixture(amd, oracle, name, tag, size
     assert abs(float(loss) - float(g["loss"])) <= 5e-3 * float(g["loss"])
 
 
-@pytest.mark.parametrize("name,tag,size", [("A", "bf16", 512), ("C", "f16", 256), ("B", "bf16", 256)])
+@pytest.mark.parametrize("name,tag,size", [("A", "bf16", 512), ("C", "f16", 128), ("B", "bf16", 256)])
 def test_autocast_features_no_further_from_exact_than_the_reference(amd, oracle, name, tag, size):
     """End-to-end pre-VQ features of the 68 / 74-block encoders at the fixture batch: HIP 16-bit, the reference's 16-bit
     evaluation (the oracle under CPU autocast: bit-identical to the reference, tests/test_oracle_golden.py) and an fp64
     evaluation with NO rounding points (fp32 weights widened) of the same input.  Criterion without a chosen fraction:
     ||hip16 - exact|| <= 1.25 ||ref16 - exact|| (RMS over all features, and max) -- the HIP path is no further from the
-    true value than the reference's own 16-bit arithmetic is."""
+    true value than the reference's own 16-bit arithmetic is.  (cfg C: a 128 x 128 crop of the fixture patch -- the f16 autocast of
+    the 256-channel model on the CPU, twice, is what bounds this test's run time; the encoder is fully convolutional.)"""
     from conftest import record_parity
     g = load_golden(f"model_{name}_{tag}")
     spec = oracle.SPECS[name]
     p = params_for(oracle, name, g)
     B = int(g["batch"])
-    x = oracle.make_patches(B, size, 0)
+    x = oracle.make_patches(B, max(size, 256), 0)[:, :, :size, :size].contiguous()
     nat = amd.NativeVQAE(amd.SPECS[name], p, compute_dtype=tag)
     z_hip = nat.encode_features(x.cuda()).permute(0, 3, 1, 2).cpu().double()
     projected = spec.projection_dim > 0                 # the handle then reports the projected features (vq.py:190)

@@ -26,6 +26,13 @@ size_t wino_weight_floats(int c);
 int wino_transform_weight(const float* w_oihw_dev, int c, int dtype, float* U_dev, hipStream_t stream);
 int wino_frag_weight(const float* w_packed_dev, int c, int sk, float* out_dev, hipStream_t stream);
 int conv_tail_kslice(int dtype, int cin);
+bool wino43_supported(int c, int h, int w, int dtype);
+bool wino43_enabled();
+size_t wino43_weight_floats(int c);
+int wino43_transform_weight(const float* w_oihw_dev, int c, float* U_dev, hipStream_t stream);
+int wino43_trunk_tail(const float* t1, const float* U, const float* w3, float act_a, float act_b, float t_scale, float t_b4,
+                      float* xio, const float* w1n, float n_b1a, float n_b1b, float n_b2a, float n_b2b, float* t1_next,
+                      int batch, int h, int w, int c, hipStream_t stream);
 int wino_trunk_tail(const float* t1, const float* U, const float* w3, float act_a, float act_b, float t_scale, float t_b4,
                     float* xio, const float* w1n, float n_b1a, float n_b1b, float n_b2a, float n_b2b, float* t1_next,
                     int batch, int h, int w, int c, int dtype, hipStream_t stream);
@@ -129,6 +136,7 @@ struct Block {
     int mode, cin, cout, br;
     float b1a, b1b, b2a, b2b, b3a, b3b, b4, scale, b1c, b1d;
     float *w1, *w2, *w3, *wskip;          // packed, device
+    float* wU43 = nullptr;                // F(4x4, 3x3)-domain conv2 weights [36][C][C] (fp32, C = 128, conv_wino43.hip)
     float* wU = nullptr;                  // Winograd-domain conv2 weights [16][C][C] (fp32 trunk blocks, C = 64 / 128, conv_wino.hip)
     float *w1f = nullptr, *w3f = nullptr; // conv1 / conv3 weights in MFMA fragment order for the fused tails (both trunk kernels)
     float *w2f = nullptr, *wskf = nullptr;// 'down' blocks: conv2 / skip_conv in fragment order too (down_fused.hip)
@@ -249,6 +257,22 @@ int upload_wino(vqae_handle* h, const float* host, int c, float** out) {
     return rc;
 }
 
+// conv2 weights [c][c][3][3] (host, PyTorch layout) -> F(4x4, 3x3) domain on the device (conv_wino43.hip)
+int upload_wino43(vqae_handle* h, const float* host, int c, float** out) {
+    void* tmp = nullptr;
+    const size_t raw = (size_t)c * c * 9 * 4;
+    if (hipMalloc(&tmp, raw) != hipSuccess) return vqae::fail(VQAE_ERR_NOMEM, "hipMalloc failed");
+    hipError_t e = hipMemcpy(tmp, host, raw, hipMemcpyHostToDevice);
+    void* U = nullptr;
+    int rc = (e == hipSuccess) ? dev_alloc(h, vqae::wino43_weight_floats(c) * 4, &U)
+                               : vqae::fail(VQAE_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(e));
+    if (rc == VQAE_OK) rc = vqae::wino43_transform_weight((const float*)tmp, c, (float*)U, nullptr);
+    if (rc == VQAE_OK && hipDeviceSynchronize() != hipSuccess) rc = vqae::fail(VQAE_ERR_HIP, "winograd weight transform failed");
+    (void)hipFree(tmp);
+    *out = (float*)U;
+    return rc;
+}
+
 int scalar(const TensorMap& tm, const std::string& name, float* out) {
     const float* p;
     int rc = find(tm, name, 1, &p);
@@ -271,10 +295,13 @@ int load_block(vqae_handle* h, const TensorMap& tm, const std::string& pre, int 
     if ((rc = upload_packed(h, p, b->br, cin, 1, &b->w1))) return rc;
     if ((rc = find(tm, pre + ".branch_conv2.weight", (int64_t)b->br * b->br * k2 * k2, &p))) return rc;
     if ((rc = upload_packed(h, p, b->br, b->br, k2, &b->w2))) return rc;
-    b->wU = b->w1f = b->w3f = nullptr;
+    b->wU = b->wU43 = b->w1f = b->w3f = nullptr;
     const bool wino = mode == MODE_SAME && cout == cin && h->use_wino &&       // conv_wino.hip: fp32 C = 32/64/128; 16-bit C = 32
                       (h->cfg.compute_dtype == VQAE_DT_F32 ? (cin == 256 || cin == 128 || cin == 64 || cin == 32) : cin == 32);
     if (wino && (rc = upload_wino(h, p, cin, &b->wU))) return rc;
+    // the code-grid trunk (C = 128 on a 32-wide grid; the grid is not known here, vqae::wino43_supported decides per launch)
+    if (wino && h->cfg.compute_dtype == VQAE_DT_F32 && cin == 128 && vqae::wino43_enabled() &&
+        (rc = upload_wino43(h, p, cin, &b->wU43))) return rc;
     if ((rc = find(tm, pre + ".branch_conv3.weight", (int64_t)cout * b->br, &p))) return rc;
     if ((rc = upload_packed(h, p, cout, b->br, 1, &b->w3))) return rc;
     if (wino || (mode == MODE_SAME && (cin == 128 || cin == 64) && cout == cin)) {      // blocks that run a fused-tail kernel
@@ -520,6 +547,14 @@ int run_block(vqae_handle* h, const Block& b, const Block* next, int B, int& H, 
             }
         }
         const bool chain = next && next->mode == MODE_SAME && next->cin == b.cin && next->cout == b.cin && (!wino || next->w1f);
+        if (wino && b.wU43 && vqae::wino43_supported(b.cin, H, W, g_dt)) {
+            if ((rc = vqae::wino43_trunk_tail(P, b.wU43, b.w3f, b.b3a, b.b3b, b.scale, b.b4, X, chain ? next->w1f : nullptr,
+                                              chain ? next->b1a : 0.f, chain ? next->b1b : 0.f, chain ? next->b2a : 0.f,
+                                              chain ? next->b2b : 0.f, chain ? Q : nullptr, B, H, W, b.cin, st))) return rc;
+            if (chain) std::swap(h->buf[1], h->buf[2]);
+            h->t1_ready = chain;
+            return VQAE_OK;
+        }
         if (wino) {
             if ((rc = vqae::wino_trunk_tail(P, b.wU, b.w3f, b.b3a, b.b3b, b.scale, b.b4, X, chain ? next->w1f : nullptr,
                                             chain ? next->b1a : 0.f, chain ? next->b1b : 0.f, chain ? next->b2a : 0.f,

@@ -212,6 +212,43 @@ def test_winograd_trunk_equals_direct(amd, oracle, monkeypatch):
     assert bad_clear == 0 and bad <= max(2, n // 2000), (bad_clear, bad, n)
 
 
+def test_wino43_trunk_equals_f23_and_direct(amd, oracle, monkeypatch):
+    """The C = 128 trunk blocks on the 32-wide code grid run conv2 as Winograd F(4x4, 3x3) (csrc/conv_wino43.hip) when the grid has a
+    multiple of 8 rows; VQAE_WINO43=0 keeps F(2x2, 3x3), VQAE_NO_WINOGRAD=1 the direct implicit GEMM.  Same function, different fp32
+    rounding -- F(4x4, 3x3)'s transforms carry entries up to 8, so its distance to the direct form is a few times F(2x2, 3x3)'s
+    (DESIGN.md section 2): pre-VQ features agree to <= 1e-4 of their range after 68 blocks, indices on every row outside the rounding
+    band, the decoder output to <= 1e-6 MSE.  Grids 32 wide and 8 (all rows wrap) / 16 / 32 / 64 high, odd batches; a 4-row grid
+    falls back to F(2x2, 3x3) and must then be bit-identical to it."""
+    g = load_golden("model_B")
+    spec, p = golden_params(oracle, "B", g)
+    w43 = amd.NativeVQAE(amd.SPECS["B"], p)
+    monkeypatch.setenv("VQAE_WINO43", "0")
+    w23 = amd.NativeVQAE(amd.SPECS["B"], p)
+    monkeypatch.setenv("VQAE_NO_WINOGRAD", "1")
+    direct = amd.NativeVQAE(amd.SPECS["B"], p)
+    from conftest import record_parity
+    for (B, H, W) in ((2, 256, 256), (3, 128, 256), (1, 512, 256), (5, 64, 256), (3, 32, 256)):
+        x = oracle.make_patches(B, 512, 17)[:, :, :H, :W].contiguous().cuda()
+        z4, z2, zd = w43.encode_features(x), w23.encode_features(x), direct.encode_features(x)
+        sc = float(zd.abs().max())
+        rel4, rel2 = float((z4 - zd).abs().max()) / sc, float((z2 - zd).abs().max()) / sc
+        out4, idx4, loss4 = w43.forward(x)
+        outd, idxd, lossd = direct.forward(x)
+        agree = float((idx4 == idxd).float().mean())
+        q = direct.encode(x)[0]
+        mse = float(((w43.decode(q) - direct.decode(q)) ** 2).mean())
+        print(f"F(4,3) vs direct {B}x{H}x{W}: z rel err {rel4:.2e} (F(2,3): {rel2:.2e}), idx agreement {agree:.5f}, decoder mse {mse:.2e}")
+        record_parity("wino43_vs_direct", B=B, H=H, W=W, z_rel_err=rel4, z_rel_err_f23=rel2, idx_agreement=agree, decoder_mse=mse)
+        if H == 32:
+            assert torch.equal(z4, z2)                                  # 4-row grid: the F(2x2, 3x3) kernel on both handles
+        assert rel4 <= 1e-4 and agree >= 0.999 and mse <= 1e-6
+        assert abs(float(loss4) - float(lossd)) <= 1e-4 * float(lossd)
+    # the fixture of the reference itself through the F(4x4, 3x3) path (default handle): every index, bit for bit
+    xg = oracle.make_patches(int(g["batch"]), 256, 0).cuda()
+    _, idx, _ = w43.forward(xg)
+    assert np.array_equal(idx.cpu().numpy().reshape(-1), g["idx"].astype(np.int64).reshape(-1))
+
+
 def test_fused_down_and_up_blocks_equal_unfused(amd, oracle, monkeypatch):
     """'down' blocks in one launch (csrc/down_fused.hip) and the fused 'up' tails (up_tail_kernel) against the
     conv-by-conv path (VQAE_NO_DOWN_FUSION / VQAE_NO_UP_TAIL_FUSION): same arithmetic, different summation order."""

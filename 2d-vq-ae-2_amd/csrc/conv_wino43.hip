@@ -23,6 +23,8 @@
 // d4 + c1 d1 + c2 d2 + c3 d3 and folds Y_a += a_a Z differ in coefficients only); xi = 0 and 5 are specialised (three rows, one Y row).
 // Tails: output rows {0, 1} of every tile (image rows {0, 1, 4, 5} of the 8) form the first 128-pixel half, rows {2, 3} the second;
 // each half is t2 -> LDS [128 px][132], conv3, epilogue, next conv1 exactly as in wino_trunk_kernel.
+// The same kernel serves the levels above the trunk (C = 64 on the 64-wide grid: 2 slices x 2 tile groups; C = 32 on the 128-wide
+// grid: 1 slice x 4 tile groups) and C = 256 on the code grid (8 slices, 512 threads, one workgroup per CU).
 #include "common.h"
 
 namespace {
@@ -40,11 +42,33 @@ struct W43K {
     float* xio;                          // [M][C] residual stream, updated in place
     float* y2;                           // [M][C] next block's t1 (TAIL == 2)
     int H, M;
+    int stag, first_gen;                 // experiment: delay (x 1024 cycles) of the odd-slot workgroups among the first first_gen
     float act_a, act_b, t_scale, t_b4, n_b1a, n_b1b, n_b2a, n_b2b;
 };
 
-constexpr int C = 128, W = 32, LDT = C + 4, KG = C / 16, TILES = 16, KS = C / 8;
-constexpr int LDS_BYTES = 128 * LDT * 4;             // T[128][LDT]; V[6][16][LDT] (50 688 B) overlays it
+// (C, grid width): (256, 32) [512 threads, one workgroup per CU], (128, 32), (64, 64), (32, 128): 8 image rows x the whole grid width
+template <int C_> struct W43Cfg {
+    static constexpr int C = C_;
+    static constexpr int W = C >= 128 ? 32 : (C == 64 ? 64 : 128);
+    static constexpr int NT = C == 256 ? 512 : 256;
+    static constexpr int NWV = NT / 64;
+    static constexpr int NS = C / 32;                  // 32-channel slices
+    static constexpr int TG = NWV / NS;                // 16-tile groups (a wave = one slice x one group)
+    static constexpr int TILES = 16 * TG;              // = 2 tile rows x W / 4 tile columns
+    static constexpr int TC = W / 4;
+    static constexpr int PXH = 4 * W;                  // pixels of one half (4 of the 8 rows)
+    static constexpr int C4 = C / 4;
+    static constexpr int RP = NT / C4;                 // pixels one sweep of the workgroup's threads covers (= TC)
+    static constexpr int LDT = C + 4;
+    static constexpr int KG = C / 16;                  // k-groups (16 channels = 4 MFMAs per block) per position
+    static constexpr int KS = C / 8;                   // tails: k-slices
+    static constexpr int NI = C >= 64 ? 2 : 1;         // tails: 32-channel tiles per wave
+    static constexpr int WN = C / (32 * NI);           //        waves along the channels
+    static constexpr int MI = PXH / ((NWV / WN) * 32); //        32-pixel tiles per wave (MI * NI = 4 accumulators)
+    static constexpr int V_BYTES = 6 * TILES * LDT * 4, T_BYTES = PXH * LDT * 4;
+    static constexpr int LDS_BYTES = V_BYTES > T_BYTES ? V_BYTES : T_BYTES;
+    static_assert(TILES == 2 * TC && RP == TC && PXH / RP == 16 && MI * NI == 4, "geometry");
+};
 #ifndef W43_RD
 #define W43_RD 4
 #endif
@@ -52,7 +76,7 @@ constexpr int LDS_BYTES = 128 * LDT * 4;             // T[128][LDT]; V[6][16][LD
 #define W43_NRES0 4
 #endif
 #ifndef W43_EARLY
-#define W43_EARLY 0
+#define W43_EARLY 1
 #endif
 constexpr int EARLY = W43_EARLY;                      // input batches of the next pass requested before the fold over xi (0, 1, 2)
 constexpr int RD = W43_RD;                                // weight-fragment ring depth (k-groups of 8 MFMAs = 256 MFMA cycles each)
@@ -70,16 +94,23 @@ __device__ __forceinline__ f32x4 ldg(const float* sbase, unsigned voff_bytes) {
 
 template <int N> struct IC { static constexpr int value = N; };
 
-template <int TAIL>
-__global__ __launch_bounds__(256, 2)
+template <int C, int TAIL>
+__global__ __launch_bounds__((W43Cfg<C>::NT), (W43Cfg<C>::NT == 512 ? 1 : 2))
 void wino43_trunk_kernel(const W43K p) {
+    using K = W43Cfg<C>;
+    constexpr int W = K::W, LDT = K::LDT, KG = K::KG, KS = K::KS, TILES = K::TILES, TC = K::TC, NS = K::NS, C4 = K::C4, RP = K::RP;
+    constexpr int MI = K::MI, NI = K::NI, WN = K::WN;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 15, q = lane >> 4;                         // main phase: tile, channel quad of the 16-channel block
-    const int ns = wave;                                             // main phase: 32-channel slice
+    const int li = lane & 15, q = lane >> 4;                         // main phase: tile of the group, channel quad of the 16-channel block
+    const int ns = wave % NS, tg = wave / NS;                        // main phase: 32-channel slice, 16-tile group
 
+    if (p.stag > 0 && (int)blockIdx.x < p.first_gen) {
+        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);       // HW_ID.wave_id
+        if (slot & 1) for (int i = 0; i < p.stag; ++i) __builtin_amdgcn_s_sleep(16);
+    }
     int tile_m;                                                      // XCD-contiguous order (conv_wino.hip)
     {
         const int nwg = gridDim.x, bid = blockIdx.x;
@@ -92,7 +123,7 @@ void wino43_trunk_kernel(const W43K p) {
     const float* const xim = p.t1 + (int64_t)img * p.H * W * C;
 
     // ---- transform geometry: thread -> channel quad cg, tile column tj, both tile rows ------------------------------------
-    const int cg = tid & 31, tj = tid >> 5;
+    const int cg = tid % C4, tj = tid / C4;
     unsigned coff[6];                                                // per-lane byte offsets of the unit's 6 columns
     int roff[2][6];                                                  // uniform float offsets of its 6 rows
 #pragma unroll
@@ -117,7 +148,11 @@ void wino43_trunk_kernel(const W43K p) {
             const int row = KIND == 0 ? 2 * i : (KIND == 5 ? 2 * i + 1 : i + 1);
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj)
+#ifdef W43_DBG_NOLOAD
+                d[bf][i][jj] = f32x4{1.f, 2.f, (float)i, (float)tid};
+#else
                 d[bf][i][jj] = ldg(xim + roff[s][row], coff[2 * cp + jj]);
+#endif
         }
     };
     auto combine = [&](auto kind_c, int k, float c1, float c2, float c3) __attribute__((always_inline)) {
@@ -130,7 +165,7 @@ void wino43_trunk_kernel(const W43K p) {
         }
     };
     auto columns = [&](int s) __attribute__((always_inline)) {                                      // (w B)[nu] -> V[nu][tile][c]
-        float* const dst = lds + (s * 8 + tj) * LDT + 4 * cg;
+        float* const dst = lds + (s * TC + tj) * LDT + 4 * cg;
         const f32x4 t1 = fma4(w[2], -4.f, w[4]), t2 = fma4(w[1], -4.f, w[3]);
         const f32x4 t3 = w[4] - w[2], t4 = w[3] - w[1];
         *reinterpret_cast<f32x4*>(dst + 0 * TILES * LDT) = fma4(w[0], 4.f, fma4(w[2], -5.f, w[4]));
@@ -144,7 +179,7 @@ void wino43_trunk_kernel(const W43K p) {
     // weights: this wave's 16 KiB of a position are contiguous ([k-group][block][lane][4]); positions C * C floats apart
     const float* const ub = p.U + ns * (KG * 512);                   // uniform; + 16 lane bytes per lane
     const unsigned wl = 16u * lane;
-    const float* const bfrag = lds + li * LDT + 4 * q;              // V fragment base, + nu * TILES * LDT + 16 kg
+    const float* const bfrag = lds + (16 * tg + li) * LDT + 4 * q;  // V fragment base, + nu * TILES * LDT + 16 kg
 
     f32x4 Y[4][4][2];                                                // [a][b][block]: conv2 output (4 a' + a, 4 b' + b) of tile li, 4 channels
 #pragma unroll
@@ -239,8 +274,19 @@ void wino43_trunk_kernel(const W43K p) {
 #undef WB
         // the next pass's first input batches go out before the fold over xi and the barrier
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (NEXT >= 0 && EARLY >= 1) issue(next_c, 0);
-        if constexpr (NEXT >= 0 && EARLY >= 2) issue(next_c, 1);
+        if constexpr (NEXT == 9) {                                   // inside the xi = 1..4 loop: rows (1, 2, 3, 4) of pass xi + 1 <= 4, rows (1, 3, 5, -) of pass 5
+#pragma unroll
+            for (int k = 0; k < EARLY; ++k)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ro = xi < 4 ? roff[0][i + 1] : roff[0][i < 3 ? 2 * i + 1 : 5];
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) d[k & 1][i][jj] = ldg(xim + ro, coff[2 * k + jj]);
+                }
+        } else {
+            if constexpr (NEXT >= 0 && EARLY >= 1) issue(next_c, 0);
+            if constexpr (NEXT >= 0 && EARLY >= 2) issue(next_c, 1);
+        }
         // fold over xi: Y[a][b] += A^T[a][xi] Z[b]
 #pragma unroll
         for (int b = 0; b < 4; ++b)
@@ -274,71 +320,72 @@ void wino43_trunk_kernel(const W43K p) {
         const bool lo = xi <= 2;
         const float c1 = lo ? -4.f * sg : -2.f * sg, c2 = lo ? -4.f : -1.f, c3 = lo ? sg : 2.f * sg;
         const float a1 = lo ? sg : 2.f * sg, a2 = lo ? 1.f : 4.f, a3 = lo ? sg : 8.f * sg;
-        if (EARLY == 0 || xi < 4) pass(IC<1>{}, IC<1>{}, xi, c1, c2, c3, a1, a2, a3);
-        else pass(IC<1>{}, IC<5>{}, xi, c1, c2, c3, a1, a2, a3);
+        pass(IC<1>{}, IC<9>{}, xi, c1, c2, c3, a1, a2, a3);
     }
     pass(IC<5>{}, IC<-1>{}, 5, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
 
     // ---- tails on two 128-pixel halves: half hf = output rows 2 hf, 2 hf + 1 of every tile = image rows row0 + {0, 1, 4, 5} + 2 hf ----
     float* const T = lds;
     const int li32 = lane & 31, hh = lane >> 5;                      // 32x32x2 layout of the tails
-    const int wm = wave >> 1, wn = wave & 1;                         // 64 pixels x 64 channels per wave
-    const int tj0 = tid >> 5;                                        // row-coalesced view: thread (cg, tj0) owns pixels tj0 + 8 i
+    const int wm = wave / WN, wn = wave % WN;                        // MI * 32 pixels x NI * 32 channels per wave
+    const int tj0 = tj;                                              // row-coalesced view: thread (cg, tj0) owns pixels tj0 + RP i of the half
     float* const trow = T + tj0 * LDT + 4 * cg;
-    const int ty = li >> 3, tx = li & 7;
-    f32x4 bt[RT][2];
+    const int ty = (16 * tg + li) / TC, tx = (16 * tg + li) % TC;
+    f32x4 bt[RT][NI];
     auto tail_prefetch = [&](const float* __restrict__ wsrc) __attribute__((always_inline)) {
-        const float* b0 = wsrc + (wn * 2) * (KS * 256);
+        const float* b0 = wsrc + (wn * NI) * (KS * 256);
 #pragma unroll
         for (int u = 0; u < RT; ++u)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) bt[u][ni] = ldg(b0 + ni * (KS * 256) + 256 * u, wl);
+            for (int ni = 0; ni < NI; ++ni) bt[u][ni] = ldg(b0 + ni * (KS * 256) + 256 * u, wl);
     };
-    f32x16 acc[2][2];
+    f32x16 acc[MI][NI];
     auto gemm_tail = [&](const float* __restrict__ wsrc) __attribute__((always_inline)) {
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+            for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-        const float* a0 = T + (wm * 64 + li32) * LDT + 4 * hh;
-        const float* b0 = wsrc + (wn * 2) * (KS * 256);
-        f32x4 a[2][2];
+        const float* a0 = T + (wm * MI * 32 + li32) * LDT + 4 * hh;
+        const float* b0 = wsrc + (wn * NI) * (KS * 256);
+        f32x4 a[2][MI];
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) a[0][mi] = *reinterpret_cast<const f32x4*>(a0 + mi * 32 * LDT);
+        for (int mi = 0; mi < MI; ++mi) a[0][mi] = *reinterpret_cast<const f32x4*>(a0 + mi * 32 * LDT);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if (ks + 1 < KS) {
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) a[(ks + 1) & 1][mi] = *reinterpret_cast<const f32x4*>(a0 + mi * 32 * LDT + 8 * (ks + 1));
+                for (int mi = 0; mi < MI; ++mi) a[(ks + 1) & 1][mi] = *reinterpret_cast<const f32x4*>(a0 + mi * 32 * LDT + 8 * (ks + 1));
             }
-            const f32x4 b_0 = bt[ks % RT][0], b_1 = bt[ks % RT][1];
+            f32x4 bc[NI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) bc[ni] = bt[ks % RT][ni];
             if (ks + RT < KS) {
-                bt[ks % RT][0] = ldg(b0 + 256 * (ks + RT), wl);
-                bt[ks % RT][1] = ldg(b0 + KS * 256 + 256 * (ks + RT), wl);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) bt[ks % RT][ni] = ldg(b0 + ni * (KS * 256) + 256 * (ks + RT), wl);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
-                    acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_0[r], a[ks & 1][mi][r], acc[mi][0], 0, 0, 0);
-                    acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b_1[r], a[ks & 1][mi][r], acc[mi][1], 0, 0, 0);
-                }
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(bc[ni][r], a[ks & 1][mi][r], acc[mi][ni], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
     auto acc_to_lds = [&]() __attribute__((always_inline)) {                                         // D[channel][pixel] -> T[pixel][channel], 128-bit writes
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = acc[mi][ni][4 * g + e];
-                    *reinterpret_cast<f32x4*>(T + (wm * 64 + mi * 32 + li32) * LDT + (wn * 2 + ni) * 32 + 8 * g + 4 * hh) = o;
+                    *reinterpret_cast<f32x4*>(T + (wm * MI * 32 + mi * 32 + li32) * LDT + (wn * NI + ni) * 32 + 8 * g + 4 * hh) = o;
                 }
     };
 
@@ -365,12 +412,12 @@ void wino43_trunk_kernel(const W43K p) {
         f32x4 res[16];
         constexpr int NRES0 = W43_NRES0;
 #pragma unroll
-        for (int i = 0; i < (hf == 0 ? NRES0 : 16); ++i) res[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr[i >> 2] + (8 * (i & 3)) * C));
+        for (int i = 0; i < (hf == 0 ? NRES0 : 16); ++i) res[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr[(RP * i) / W] + ((RP * i) % W) * C));
         lds_barrier();                                               // t2 complete
         gemm_tail(p.w3);                                             // conv3
         if (hf == 0) {
 #pragma unroll
-            for (int i = NRES0; i < 16; ++i) res[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr[i >> 2] + (8 * (i & 3)) * C));
+            for (int i = NRES0; i < 16; ++i) res[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr[(RP * i) / W] + ((RP * i) % W) * C));
         }
         if (TAIL == 2) tail_prefetch(p.w1n);
         lds_barrier();                                               // every wave is done reading t2
@@ -379,15 +426,15 @@ void wino43_trunk_kernel(const W43K p) {
         // out = conv3 * scale + bias4 + x, in place over the residual stream, whole pixel rows per 8th of a workgroup
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            f32x4 t = *reinterpret_cast<const f32x4*>(trow + 8 * i * LDT);
+            f32x4 t = *reinterpret_cast<const f32x4*>(trow + RP * i * LDT);
             t = t * p.t_scale;
             t = t + p.t_b4;
             t = t + res[i];
-            __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(xr[i >> 2] + (8 * (i & 3)) * C));
+            __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(xr[(RP * i) / W] + ((RP * i) % W) * C));
             if (TAIL == 2) {                                          // next block's conv1 pre-op, back into T in place
 #pragma unroll
                 for (int e = 0; e < 4; ++e) t[e] = elu_act(t[e] + p.n_b1a) + p.n_b1b;
-                *reinterpret_cast<f32x4*>(trow + 8 * i * LDT) = t;
+                *reinterpret_cast<f32x4*>(trow + RP * i * LDT) = t;
             }
         }
         if constexpr (TAIL == 2) {
@@ -399,11 +446,11 @@ void wino43_trunk_kernel(const W43K p) {
             float* const y0 = p.y2 + (xr[0] - p.xio);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                f32x4 t = *reinterpret_cast<const f32x4*>(trow + 8 * i * LDT);
+                f32x4 t = *reinterpret_cast<const f32x4*>(trow + RP * i * LDT);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) t[e] = elu_act(t[e] + p.n_b2a) + p.n_b2b;
-                const int r = i >> 2;
-                __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(y0 + ((4 * (r >> 1) + (r & 1)) * W + 8 * (i & 3)) * C));
+                const int r = (RP * i) / W;
+                __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(y0 + ((4 * (r >> 1) + (r & 1)) * W + (RP * i) % W) * C));
             }
         }
         if (hf == 0) lds_barrier();                                  // T is rewritten by the second half's t2
@@ -437,7 +484,8 @@ namespace vqae {
 
 // geometry only; whether a handle uses this form at all is decided when it is created (VQAE_WINO43=0: F(2x2, 3x3) everywhere)
 bool wino43_supported(int c, int h, int w, int dtype) {
-    return dtype == VQAE_DT_F32 && c == C && w == W && h >= 8 && h % 8 == 0;
+    const bool cw = (c == 256 && w == 32) || (c == 128 && w == 32) || (c == 64 && w == 64) || (c == 32 && w == 128);
+    return dtype == VQAE_DT_F32 && cw && h >= 8 && h % 8 == 0;
 }
 bool wino43_enabled() {
     const char* e = getenv("VQAE_WINO43");
@@ -448,8 +496,28 @@ size_t wino43_weight_floats(int c) { return (size_t)36 * c * c; }
 
 // w_oihw_dev [c][c][3][3] (PyTorch layout, device) -> U_dev [36][c][c] (fragment order above)
 int wino43_transform_weight(const float* w_oihw_dev, int c, float* U_dev, hipStream_t stream) {
-    VQAE_REQUIRE(c == C, VQAE_ERR_UNSUPPORTED, "wino43_transform_weight: C = %d", c);
+    VQAE_REQUIRE(c == 256 || c == 128 || c == 64 || c == 32, VQAE_ERR_UNSUPPORTED, "wino43_transform_weight: C = %d", c);
     wino43_weight_kernel<<<(unsigned)ceil_div(c * c, 256), 256, 0, stream>>>(w_oihw_dev, c, U_dev);
+    VQAE_LAUNCH_CHECK();
+    return VQAE_OK;
+}
+
+template <int C>
+static int launch_w43(W43K& k, int64_t M, bool chain, hipStream_t stream) {
+    using K = W43Cfg<C>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)wino43_trunk_kernel<C, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES));
+        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)wino43_trunk_kernel<C, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES));
+        attr_set = true;
+    }
+    const unsigned grid = (unsigned)(M / (8 * K::W));
+    // executed matrix work: 36 GEMMs of K = C per 16 output pixels (K_eff = 2.25 C per pixel) + the 1x1 tails
+    const double flops = 2.0 * (double)M * C * (2.25 * C + C + (chain ? C : 0));
+    ProfScope prof(C >= 128 ? PROF_CONV3X3_TRUNK : PROF_NONE, stream, flops);
+    if (chain) wino43_trunk_kernel<C, 2><<<grid, K::NT, K::LDS_BYTES, stream>>>(k);
+    else wino43_trunk_kernel<C, 1><<<grid, K::NT, K::LDS_BYTES, stream>>>(k);
+    prof.done();
     VQAE_LAUNCH_CHECK();
     return VQAE_OK;
 }
@@ -460,30 +528,23 @@ int wino43_trunk_tail(const float* t1, const float* U, const float* w3, float ac
                       int batch, int h, int w, int c, hipStream_t stream) {
     if (batch == 0) return VQAE_OK;
     VQAE_REQUIRE(t1 && U && w3 && xio && (!w1n || t1_next), VQAE_ERR_INVALID, "wino43_trunk_tail: null pointer");
-    VQAE_REQUIRE(c == C && w == W && h >= 8 && h % 8 == 0, VQAE_ERR_UNSUPPORTED, "wino43_trunk_tail: C = %d, H = %d, W = %d", c, h, w);
+    VQAE_REQUIRE(wino43_supported(c, h, w, VQAE_DT_F32), VQAE_ERR_UNSUPPORTED, "wino43_trunk_tail: C = %d, H = %d, W = %d", c, h, w);
     const int64_t M = (int64_t)batch * h * w;
-    VQAE_REQUIRE(M < (1ll << 31) - 256, VQAE_ERR_UNSUPPORTED, "wino43_trunk_tail: too many pixels");
-    static bool attr_set = false;
-    if (!attr_set) {
-        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)wino43_trunk_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)wino43_trunk_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_set = true;
-    }
+    VQAE_REQUIRE(M < (1ll << 31) - 1024, VQAE_ERR_UNSUPPORTED, "wino43_trunk_tail: too many pixels");
     W43K k;
     memset(&k, 0, sizeof(k));
     k.t1 = t1; k.U = U; k.w3 = w3; k.w1n = w1n; k.xio = xio; k.y2 = t1_next;
     k.H = h; k.M = (int)M;
     k.act_a = act_a; k.act_b = act_b; k.t_scale = t_scale; k.t_b4 = t_b4;
     k.n_b1a = n_b1a; k.n_b1b = n_b1b; k.n_b2a = n_b2a; k.n_b2b = n_b2b;
-    const unsigned grid = (unsigned)(M / 256);
-    // executed matrix work: 36 GEMMs of K = C per 16 output pixels (K_eff = 2.25 C per pixel) + the 1x1 tails
-    const double flops = 2.0 * (double)M * C * (2.25 * C + C + (w1n ? C : 0));
-    ProfScope prof(PROF_CONV3X3_TRUNK, stream, flops);
-    if (w1n) wino43_trunk_kernel<2><<<grid, 256, LDS_BYTES, stream>>>(k);
-    else wino43_trunk_kernel<1><<<grid, 256, LDS_BYTES, stream>>>(k);
-    prof.done();
-    VQAE_LAUNCH_CHECK();
-    return VQAE_OK;
+    static const int stag = getenv("VQAE_W43_STAG") ? atoi(getenv("VQAE_W43_STAG")) : 0;
+    k.stag = stag; k.first_gen = 512;
+    switch (c) {
+        case 256: return launch_w43<256>(k, M, w1n != nullptr, stream);
+        case 128: return launch_w43<128>(k, M, w1n != nullptr, stream);
+        case 64: return launch_w43<64>(k, M, w1n != nullptr, stream);
+        default: return launch_w43<32>(k, M, w1n != nullptr, stream);
+    }
 }
 
 }  // namespace vqae

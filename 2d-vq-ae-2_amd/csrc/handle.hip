@@ -299,8 +299,9 @@ int load_block(vqae_handle* h, const TensorMap& tm, const std::string& pre, int 
     const bool wino = mode == MODE_SAME && cout == cin && h->use_wino &&       // conv_wino.hip: fp32 C = 32/64/128; 16-bit C = 32
                       (h->cfg.compute_dtype == VQAE_DT_F32 ? (cin == 256 || cin == 128 || cin == 64 || cin == 32) : cin == 32);
     if (wino && (rc = upload_wino(h, p, cin, &b->wU))) return rc;
-    // the code-grid trunk (C = 128 on a 32-wide grid; the grid is not known here, vqae::wino43_supported decides per launch)
-    if (wino && h->cfg.compute_dtype == VQAE_DT_F32 && cin == 128 && vqae::wino43_enabled() &&
+    // F(4x4, 3x3) form (C = 256 / 128 on the 32-wide code grid, 64 on the 64-wide, 32 on the 128-wide level; the grid is not known
+    // here, vqae::wino43_supported decides per launch and the F(2x2, 3x3) weights stay for the other grids)
+    if (wino && h->cfg.compute_dtype == VQAE_DT_F32 && vqae::wino43_enabled() &&
         (rc = upload_wino43(h, p, cin, &b->wU43))) return rc;
     if ((rc = find(tm, pre + ".branch_conv3.weight", (int64_t)cout * b->br, &p))) return rc;
     if ((rc = upload_packed(h, p, cout, b->br, 1, &b->w3))) return rc;

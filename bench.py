@@ -251,14 +251,21 @@ def run_leg(args, ctx, headline):
                 #                  outputs) -- `achieved`/`frac` price the executed MFMA work, i.e. real pipe utilisation;
                 #                  `direct_equivalent_*` price the same launch as a direct conv (may exceed 1.0 of peak).
                 direct = 2.0 * M * C * (9 * C + C + C)
+                #   F(4x4,3x3) form (C = 128, round 3): 2*M*C*(2.25C + C + C) flop executed (36 multiplies per 16 outputs): fewer
+                #                  executed flops in less time -- the MFMA-only fraction FALLS while the launch gets faster; the
+                #                  roof that binds is MFMA + VALU issue (fp32 MFMA does not co-execute on gfx950)
                 wino = C in (256, 128, 64, 32) and not os.environ.get("VQAE_NO_WINOGRAD")
+                w43 = wino and C == 128 and zh % 8 == 0 and os.environ.get("VQAE_WINO43", "1") != "0"
                 traffic, tnote = pmc_traffic(f"{args.config}_{args.dtype}_B{B}")
-                res["roofline"] = {"kernel": "wino_trunk_kernel: trunk Fixup block, conv2 3x3 as Winograd F(2x2,3x3) + fused conv3 / "
+                res["roofline"] = {"kernel": "wino43_trunk_kernel: trunk Fixup block, conv2 3x3 as Winograd F(4x4,3x3) + fused conv3 / next-conv1 tails" if w43
+                                             else "wino_trunk_kernel: trunk Fixup block, conv2 3x3 as Winograd F(2x2,3x3) + fused conv3 / "
                                              "next-conv1 tails" if wino else "conv_mfma_kernel TAIL: trunk Fixup block, direct conv2 + fused tails",
                                    "bound": "mfma", "achieved": round(alg / (avg_ms * 1e-3) / 1e12, 2),
                                    "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "traffic": traffic, "traffic_note": tnote,
                                    "launches": k_n.value, "avg_ms": round(avg_ms, 4), "alg_flops_per_launch": alg,
-                                   "winograd": bool(wino), "direct_equivalent_tflops": round(direct / (avg_ms * 1e-3) / 1e12, 2),
+                                   "winograd": ("F(4x4,3x3)" if w43 else "F(2x2,3x3)") if wino else False,
+                                   "f23_equivalent_tflops": round(2.0 * M * C * 6 * C / (avg_ms * 1e-3) / 1e12, 2),
+                                   "direct_equivalent_tflops": round(direct / (avg_ms * 1e-3) / 1e12, 2),
                                    "direct_equivalent_frac": round(direct / (avg_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
             elif args.prof_class == 1:
                 # 16-bit trunk Fixup block kernel (csrc/trunk16.hip): direct conv2 on v_mfma_f32_32x32x16_{bf16,f16} + fused

@@ -217,8 +217,9 @@ def test_wino43_trunk_equals_f23_and_direct(amd, oracle, monkeypatch):
     multiple of 8 rows; VQAE_WINO43=0 keeps F(2x2, 3x3), VQAE_NO_WINOGRAD=1 the direct implicit GEMM.  Same function, different fp32
     rounding -- F(4x4, 3x3)'s transforms carry entries up to 8, so its distance to the direct form is a few times F(2x2, 3x3)'s
     (DESIGN.md section 2): pre-VQ features agree to <= 1e-4 of their range after 68 blocks, indices on every row outside the rounding
-    band, the decoder output to <= 1e-6 MSE.  Grids 32 wide and 8 (all rows wrap) / 16 / 32 / 64 high, odd batches; a 4-row grid
-    falls back to F(2x2, 3x3) and must then be bit-identical to it."""
+    band, the decoder output to <= 1e-6 MSE.  cfg B runs it at three levels (C = 32 on the 128-wide grid, 64 on the 64-wide, 128 on the
+    32-wide code grid); image heights 512 / 256 / 128 / 64 / 32 give grids of 64 ... 4 rows (8 rows: every row wraps; 4 rows at the code
+    grid: that level falls back to F(2x2, 3x3)), odd batches."""
     g = load_golden("model_B")
     spec, p = golden_params(oracle, "B", g)
     w43 = amd.NativeVQAE(amd.SPECS["B"], p)
@@ -239,8 +240,6 @@ def test_wino43_trunk_equals_f23_and_direct(amd, oracle, monkeypatch):
         mse = float(((w43.decode(q) - direct.decode(q)) ** 2).mean())
         print(f"F(4,3) vs direct {B}x{H}x{W}: z rel err {rel4:.2e} (F(2,3): {rel2:.2e}), idx agreement {agree:.5f}, decoder mse {mse:.2e}")
         record_parity("wino43_vs_direct", B=B, H=H, W=W, z_rel_err=rel4, z_rel_err_f23=rel2, idx_agreement=agree, decoder_mse=mse)
-        if H == 32:
-            assert torch.equal(z4, z2)                                  # 4-row grid: the F(2x2, 3x3) kernel on both handles
         assert rel4 <= 1e-4 and agree >= 0.999 and mse <= 1e-6
         assert abs(float(loss4) - float(lossd)) <= 1e-4 * float(lossd)
     # the fixture of the reference itself through the F(4x4, 3x3) path (default handle): every index, bit for bit

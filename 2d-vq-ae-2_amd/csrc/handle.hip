@@ -301,7 +301,7 @@ int load_block(vqae_handle* h, const TensorMap& tm, const std::string& pre, int 
     if (wino && (rc = upload_wino(h, p, cin, &b->wU))) return rc;
     // F(4x4, 3x3) form (C = 256 / 128 on the 32-wide code grid, 64 on the 64-wide, 32 on the 128-wide level; the grid is not known
     // here, vqae::wino43_supported decides per launch and the F(2x2, 3x3) weights stay for the other grids)
-    if (wino && h->cfg.compute_dtype == VQAE_DT_F32 && vqae::wino43_enabled() &&
+    if (wino && h->cfg.compute_dtype == VQAE_DT_F32 && vqae::wino43_enabled() && vqae::wino43_supported(cin, 8, cin >= 128 ? 32 : (cin == 64 ? 64 : 128), VQAE_DT_F32) &&
         (rc = upload_wino43(h, p, cin, &b->wU43))) return rc;
     if ((rc = find(tm, pre + ".branch_conv3.weight", (int64_t)cout * b->br, &p))) return rc;
     if ((rc = upload_packed(h, p, cout, b->br, 1, &b->w3))) return rc;

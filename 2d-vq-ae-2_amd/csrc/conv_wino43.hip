@@ -92,6 +92,14 @@ __device__ __forceinline__ f32x4 ldg(const float* sbase, unsigned voff_bytes) {
     return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(sbase) + voff_bytes);
 }
 
+// Developer aid (off by default; tools/dbg/w43_trace.py): per-phase s_memtime stamps of every wave of the chained (TAIL == 2) launches.
+#ifdef W43_TRACE
+__device__ unsigned long long* g_w43_trace = nullptr;
+#define STAMP(i) do { if (TAIL == 2 && lane == 0 && g_w43_trace) g_w43_trace[((int64_t)blockIdx.x * 8 + wave) * 64 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
 template <int N> struct IC { static constexpr int value = N; };
 
 template <int C, int TAIL>
@@ -111,6 +119,14 @@ void wino43_trunk_kernel(const W43K p) {
         const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);       // HW_ID.wave_id
         if (slot & 1) for (int i = 0; i < p.stag; ++i) __builtin_amdgcn_s_sleep(16);
     }
+#ifdef W43_TRACE
+    if (TAIL == 2 && lane == 0 && g_w43_trace) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);           // HW_ID[15:0]
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);          // XCC_ID[3:0]
+        g_w43_trace[((int64_t)blockIdx.x * 8 + wave) * 64 + 63] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
+    STAMP(0);
     int tile_m;                                                      // XCD-contiguous order (conv_wino.hip)
     {
         const int nwg = gridDim.x, bid = blockIdx.x;
@@ -192,6 +208,11 @@ void wino43_trunk_kernel(const W43K p) {
         constexpr int KIND = decltype(kind_c)::value;
         constexpr int NEXT = decltype(next_c)::value;                // kind of the following pass (-1: none)
         __builtin_amdgcn_sched_barrier(0);
+#if defined(W43_PRIO) && W43_PRIO == 1
+        __builtin_amdgcn_s_setprio(3);                               // experiment: the short load / vector phases ahead of the partner's MFMA stream
+#elif defined(W43_PRIO) && W43_PRIO == 2
+        __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
         for (int j = 0; j < 6; ++j) asm volatile("" : "+v"(coff[j]));    // opaque per pass (as uoff below): no hoisted 64-bit address per (row, column)
         if (EARLY < 1) issue(kind_c, 0);                             // (EARLY batches of this pass went out before the previous pass's fold)
@@ -223,7 +244,14 @@ void wino43_trunk_kernel(const W43K p) {
             wq[s][0] = ldg(ux + WB(s), wl);
             wq[s][1] = ldg(ux + WB(s) + 256, wl);
         }
+        STAMP(1 + 5 * xi);
+#if defined(W43_PRIO) && W43_PRIO == 1
+        __builtin_amdgcn_s_setprio(0);
+#elif defined(W43_PRIO) && W43_PRIO == 2
+        __builtin_amdgcn_s_setprio(3);                               // experiment: the MFMA phase first
+#endif
         lds_barrier();                                               // V complete
+        STAMP(2 + 5 * xi);
         f32x4 Z[4][2];
 #pragma unroll
         for (int b = 0; b < 4; ++b) { Z[b][0] = f32x4{0.f, 0.f, 0.f, 0.f}; Z[b][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -272,6 +300,7 @@ void wino43_trunk_kernel(const W43K p) {
                 asm volatile("" : "+v"(Z[0][0]), "+v"(Z[0][1]), "+v"(Z[1][0]), "+v"(Z[1][1]), "+v"(Z[2][0]), "+v"(Z[2][1]), "+v"(Z[3][0]), "+v"(Z[3][1]));
         }
 #undef WB
+        STAMP(3 + 5 * xi);
         // the next pass's first input batches go out before the fold over xi and the barrier
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (NEXT == 9) {                                   // inside the xi = 1..4 loop: rows (1, 2, 3, 4) of pass xi + 1 <= 4, rows (1, 3, 5, -) of pass 5
@@ -307,7 +336,9 @@ void wino43_trunk_kernel(const W43K p) {
 #pragma unroll
             for (int b = 0; b < 4; ++b) asm volatile("" : "+v"(Y[a][b][0]), "+v"(Y[a][b][1]));
 #endif
+        STAMP(4 + 5 * xi);
         lds_barrier();                                               // every wave is done reading V of this pass
+        STAMP(5 + 5 * xi);
     };
 
     if (EARLY >= 1) issue(IC<0>{}, 0);
@@ -413,8 +444,11 @@ void wino43_trunk_kernel(const W43K p) {
         constexpr int NRES0 = W43_NRES0;
 #pragma unroll
         for (int i = 0; i < (hf == 0 ? NRES0 : 16); ++i) res[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr[(RP * i) / W] + ((RP * i) % W) * C));
+        STAMP(31 + 8 * hf);
         lds_barrier();                                               // t2 complete
+        STAMP(32 + 8 * hf);
         gemm_tail(p.w3);                                             // conv3
+        STAMP(33 + 8 * hf);
         if (hf == 0) {
 #pragma unroll
             for (int i = NRES0; i < 16; ++i) res[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr[(RP * i) / W] + ((RP * i) % W) * C));
@@ -423,6 +457,7 @@ void wino43_trunk_kernel(const W43K p) {
         lds_barrier();                                               // every wave is done reading t2
         acc_to_lds();
         lds_barrier();
+        STAMP(34 + 8 * hf);
         // out = conv3 * scale + bias4 + x, in place over the residual stream, whole pixel rows per 8th of a workgroup
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -437,9 +472,11 @@ void wino43_trunk_kernel(const W43K p) {
                 *reinterpret_cast<f32x4*>(trow + RP * i * LDT) = t;
             }
         }
+        STAMP(35 + 8 * hf);
         if constexpr (TAIL == 2) {
             lds_barrier();
             gemm_tail(p.w1n);                                        // next block's conv1
+            STAMP(36 + 8 * hf);
             lds_barrier();                                           // every wave is done reading T
             acc_to_lds();
             lds_barrier();
@@ -453,7 +490,9 @@ void wino43_trunk_kernel(const W43K p) {
                 __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(y0 + ((4 * (r >> 1) + (r & 1)) * W + (RP * i) % W) * C));
             }
         }
+        STAMP(37 + 8 * hf);
         if (hf == 0) lds_barrier();                                  // T is rewritten by the second half's t2
+        STAMP(38 + 8 * hf);
     }
 }
 
@@ -509,17 +548,21 @@ template <int C>
 static int launch_w43(W43K& k, int64_t M, bool chain, hipStream_t stream) {
     using K = W43Cfg<C>;
     static bool attr_set = false;
+    static int pad = 0;
     if (!attr_set) {
-        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)wino43_trunk_kernel<C, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES));
-        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)wino43_trunk_kernel<C, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES));
+#ifdef W43_TRACE
+        pad = getenv("VQAE_W43_LDS_PAD") ? atoi(getenv("VQAE_W43_LDS_PAD")) : 0;      // experiment: one workgroup per CU
+#endif
+        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)wino43_trunk_kernel<C, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES + pad));
+        VQAE_HIP_CHECK(hipFuncSetAttribute((const void*)wino43_trunk_kernel<C, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES + pad));
         attr_set = true;
     }
     const unsigned grid = (unsigned)(M / (8 * K::W));
     // executed matrix work: 36 GEMMs of K = C per 16 output pixels (K_eff = 2.25 C per pixel) + the 1x1 tails
     const double flops = 2.0 * (double)M * C * (2.25 * C + C + (chain ? C : 0));
     ProfScope prof(C >= 128 ? PROF_CONV3X3_TRUNK : PROF_NONE, stream, flops);
-    if (chain) wino43_trunk_kernel<C, 2><<<grid, K::NT, K::LDS_BYTES, stream>>>(k);
-    else wino43_trunk_kernel<C, 1><<<grid, K::NT, K::LDS_BYTES, stream>>>(k);
+    if (chain) wino43_trunk_kernel<C, 2><<<grid, K::NT, K::LDS_BYTES + pad, stream>>>(k);
+    else wino43_trunk_kernel<C, 1><<<grid, K::NT, K::LDS_BYTES + pad, stream>>>(k);
     prof.done();
     VQAE_LAUNCH_CHECK();
     return VQAE_OK;
@@ -551,3 +594,9 @@ int wino43_trunk_tail(const float* t1, const float* U, const float* w3, float ac
 }
 
 }  // namespace vqae
+
+#ifdef W43_TRACE
+extern "C" int vqae_debug_w43_trace(void* dev_buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_w43_trace), &dev_buf, sizeof(dev_buf)) == hipSuccess ? 0 : -3;
+}
+#endif

@@ -66,7 +66,7 @@ def kernel_source_hash(files):
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(key):
+def pmc_traffic(key, kernel=None):
     """HBM bytes per launch of the dominant kernel from separate rocprofv3 --pmc passes (FETCH_SIZE doubled per
     MI355X_MICROARCH.md, + WRITE_SIZE), as recorded in profiles/r0N_pmc_traffic.json by tools/pmc_traffic.py.  Each
     entry carries the hash of the kernel sources it was measured on; a figure for other code is refused (null)."""
@@ -82,6 +82,8 @@ def pmc_traffic(key):
             raise KeyError(key)
         if d["source_hash"] != kernel_source_hash(d["sources"]):
             return None, f"stale: measured on sources {d['source_hash']}, kernel has changed since"
+        if kernel and not d["kernel"].startswith(kernel):
+            return None, f"not measured for {kernel} (the entry is for {d['kernel']})"
         return d["bytes_per_launch"], f"rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, sources {d['source_hash']}"
     except Exception as e:                      # no profile for this configuration
         return None, f"not measured ({type(e).__name__})"
@@ -255,8 +257,8 @@ def run_leg(args, ctx, headline):
                 #                  executed flops in less time -- the MFMA-only fraction FALLS while the launch gets faster; the
                 #                  roof that binds is MFMA + VALU issue (fp32 MFMA does not co-execute on gfx950)
                 wino = C in (256, 128, 64, 32) and not os.environ.get("VQAE_NO_WINOGRAD")
-                w43 = wino and C == 128 and zh % 8 == 0 and os.environ.get("VQAE_WINO43", "1") != "0"
-                traffic, tnote = pmc_traffic(f"{args.config}_{args.dtype}_B{B}")
+                w43 = wino and C in (128, 256) and zh % 8 == 0 and os.environ.get("VQAE_WINO43", "1") != "0"
+                traffic, tnote = pmc_traffic(f"{args.config}_{args.dtype}_B{B}", "wino43_trunk_kernel" if w43 else None)
                 res["roofline"] = {"kernel": "wino43_trunk_kernel: trunk Fixup block, conv2 3x3 as Winograd F(4x4,3x3) + fused conv3 / next-conv1 tails" if w43
                                              else "wino_trunk_kernel: trunk Fixup block, conv2 3x3 as Winograd F(2x2,3x3) + fused conv3 / "
                                              "next-conv1 tails" if wino else "conv_mfma_kernel TAIL: trunk Fixup block, direct conv2 + fused tails",

@@ -39,10 +39,11 @@ def main():
     a = ap.parse_args()
     bench_args = ["--config", a.config, "--dtype", a.dtype, "--batch", str(a.batch)]
     cch = 256 if a.config == "C" else 128                             # trunk channels: the dominant kernel's instantiation
-    kern = "wino_trunk_kernel" if a.dtype == "f32" and a.config != "C" else ("trunk16_kernel" if a.dtype != "f32" else "conv_mfma_kernel")
+    w43 = os.environ.get("VQAE_WINO43", "1") != "0"                  # round 3: the fp32 trunk runs conv_wino43.hip unless switched off
+    kern = ("wino43_trunk_kernel" if w43 else "wino_trunk_kernel") if a.dtype == "f32" else "trunk16_kernel"
     pat = f"{kern}<{cch}, "
-    sources = {"wino_trunk_kernel": ["conv_wino.hip", "common.h"], "trunk16_kernel": ["trunk16.hip", "common.h"],
-               "conv_mfma_kernel": ["conv_mfma.hip", "common.h"]}[kern]
+    sources = {"wino43_trunk_kernel": ["conv_wino43.hip", "common.h"], "wino_trunk_kernel": ["conv_wino.hip", "common.h"],
+               "trunk16_kernel": ["trunk16.hip", "common.h"]}[kern]
     tot = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         rows = [r for r in (load_pass(counter, f"{a.config}_{a.dtype}") if a.reuse else one_pass(counter, bench_args, f"{a.config}_{a.dtype}"))

@@ -235,7 +235,7 @@ class PinnedRing:
     the consumer has fetched batch k + R - in_flight >= k + 2; the consumer waits for batch k's copy event before it
     fetches batch k + 2 (run_eval), so R = in_flight + 2 slots suffice."""
 
-    def __init__(self, n_slots, n_max, img_shape, img_dtype, lab_shape, lab_dtype, pin=True):
+    def __init__(self, n_slots, n_max, img_shape, img_dtype, lab_shape, lab_dtype, pin=True, device=None):
         import mmap
         self.n_slots, self.n_max = int(n_slots), int(n_max)
         self.img_shape, self.img_dtype = tuple(img_shape), img_dtype
@@ -248,9 +248,25 @@ class PinnedRing:
         self._mm = mmap.mmap(-1, self.nbytes)                     # MAP_SHARED | MAP_ANONYMOUS: shared with forked workers
         self._buf = torch.frombuffer(self._mm, dtype=torch.uint8)
         self.pinned = False
+        self._pin_thread = None
         if pin and torch.cuda.is_available():
-            rc = torch.cuda.cudart().cudaHostRegister(self._buf.data_ptr(), self.nbytes, 0)
-            self.pinned = int(rc) == 0
+            # Page-locking a few GB takes 0.3 - 1 s: it runs beside the start of the worker processes and the production of the
+            # first batches (the workers only write into the mapping); wait_pinned() before the first DMA from it.
+            import threading
+
+            def _register():
+                if device is not None:
+                    torch.cuda.set_device(device)
+                self.pinned = int(torch.cuda.cudart().cudaHostRegister(self._buf.data_ptr(), self.nbytes, 0)) == 0
+
+            self._pin_thread = threading.Thread(target=_register, name="vqae-ring-pin")
+            self._pin_thread.start()
+
+    def wait_pinned(self):
+        if self._pin_thread is not None:
+            self._pin_thread.join()
+            self._pin_thread = None
+        return self.pinned
 
     def views(self, slot, n):
         """(imgs [n, *img_shape], labels [n, *lab_shape]) views of slot `slot`."""
@@ -260,6 +276,7 @@ class PinnedRing:
         return a, b
 
     def close(self):
+        self.wait_pinned()
         if self.pinned:
             torch.cuda.cudart().cudaHostUnregister(self._buf.data_ptr())
             self.pinned = False
@@ -366,7 +383,8 @@ def run_eval(model, dataset, batch_size=100, *, autocast_dtype=_REF_AUTOCAST, nu
     if use_ring:
         in_flight = max(1, num_workers) * (prefetch_factor if num_workers else 1)
         with _stage(timer, "host", "ring_setup"):
-            ring = PinnedRing(in_flight + 2, cap, probe[0].shape, probe[0].dtype, probe[1].shape, probe[1].dtype, pin=on_gpu)
+            ring = PinnedRing(in_flight + 2, cap, probe[0].shape, probe[0].dtype, probe[1].shape, probe[1].dtype, pin=on_gpu,
+                              device=device if on_gpu else None)
         if num_workers:
             extra["multiprocessing_context"] = "fork"              # the workers must inherit the ring's mapping
         dl = DataLoader(_RingItems(dataset, ring, send_meta=not geometry), batch_sampler=sampler,
@@ -444,6 +462,9 @@ def run_eval(model, dataset, batch_size=100, *, autocast_dtype=_REF_AUTOCAST, nu
                     if len(encoded) >= depth:
                         with _stage(timer, "host", "encoder_backpressure"):
                             encoded.pop(0).synchronize()
+                    if use_ring and k == 0:
+                        with _stage(timer, "host", "ring_pin_wait"):
+                            ring.wait_pinned()
                     with torch.cuda.stream(copy_stream):
                         with _stage(timer, "gpu", "h2d"):
                             x = imgs.to(device, non_blocking=True)
@@ -504,11 +525,25 @@ def run_eval(model, dataset, batch_size=100, *, autocast_dtype=_REF_AUTOCAST, nu
         if pending is not None:
             yield finish(pending)
     finally:
-        del it
-        if ring is not None:
-            if on_gpu:
+        # Joining the worker processes (each unmaps the ring) and un-registering the ring take 0.5 - 1 s together: once the device has
+        # drained the copies that read the ring, both run on a helper thread beside whatever the caller does next (the stitch / HDF5
+        # write of the last slide, the next dataset).  The thread is not a daemon: interpreter exit waits for it.
+        if ring is not None and on_gpu:
+            with _stage(timer, "host", "drain"):
                 torch.cuda.synchronize()
-            ring.close()
+        holder = [it]
+        del it
+
+        def _teardown(holder=holder, ring=ring):
+            holder.clear()                                         # drops the last reference: DataLoader shuts its workers down
+            if ring is not None:
+                ring.close()
+
+        if ring is not None and on_gpu:
+            import threading
+            threading.Thread(target=_teardown, name="vqae-loader-teardown").start()
+        else:
+            _teardown()
 
 
 def _stitch(sel, rc, grid):

@@ -249,20 +249,28 @@ class PinnedRing:
         self._buf = torch.frombuffer(self._mm, dtype=torch.uint8)
         self.pinned = False
         self._pin_thread = None
-        if pin and torch.cuda.is_available():
-            # Page-locking a few GB takes 0.3 - 1 s: it runs beside the start of the worker processes and the production of the
-            # first batches (the workers only write into the mapping); wait_pinned() before the first DMA from it.
-            import threading
+        self._want_pin = bool(pin) and torch.cuda.is_available()
+        self._device = device
 
-            def _register():
-                if device is not None:
-                    torch.cuda.set_device(device)
-                self.pinned = int(torch.cuda.cudart().cudaHostRegister(self._buf.data_ptr(), self.nbytes, 0)) == 0
+    def pin_async(self):
+        """Page-lock the mapping on a helper thread (a few GB take 0.3 - 1 s): called AFTER the loader has forked its workers -- a
+        fork while another thread sits inside the driver is best avoided -- so it runs beside the production of the first batches
+        (the workers only write into the mapping).  wait_pinned() before the first DMA from the ring."""
+        if not self._want_pin or self._pin_thread is not None or self.pinned:
+            return
+        import threading
 
-            self._pin_thread = threading.Thread(target=_register, name="vqae-ring-pin")
-            self._pin_thread.start()
+        def _register():
+            if self._device is not None:
+                torch.cuda.set_device(self._device)
+            self.pinned = int(torch.cuda.cudart().cudaHostRegister(self._buf.data_ptr(), self.nbytes, 0)) == 0
+
+        self._pin_thread = threading.Thread(target=_register, name="vqae-ring-pin")
+        self._pin_thread.start()
 
     def wait_pinned(self):
+        if self._pin_thread is None and not self.pinned:
+            self.pin_async()
         if self._pin_thread is not None:
             self._pin_thread.join()
             self._pin_thread = None
@@ -276,7 +284,9 @@ class PinnedRing:
         return a, b
 
     def close(self):
-        self.wait_pinned()
+        if self._pin_thread is not None:
+            self._pin_thread.join()
+            self._pin_thread = None
         if self.pinned:
             torch.cuda.cudart().cudaHostUnregister(self._buf.data_ptr())
             self.pinned = False
@@ -442,6 +452,8 @@ def run_eval(model, dataset, batch_size=100, *, autocast_dtype=_REF_AUTOCAST, nu
         main_stream, copy_stream = torch.cuda.current_stream(device), torch.cuda.Stream(device)
     with _stage(timer, "host", "loader_start"):
         it = iter(dl)
+    if ring is not None:
+        ring.pin_async()
     try:
         for k in range(n_batches):
             with _stage(timer, "host", "loader_wait"):

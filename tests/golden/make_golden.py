@@ -377,6 +377,8 @@ if __name__ == "__main__":
         gen_model_autocast("B", 2, 256, torch.bfloat16, "bf16")
         gen_model_autocast("A", 2, 512, torch.bfloat16, "bf16")      # BASELINE config #3
         gen_model_autocast("C", 1, 256, torch.float16, "f16")        # BASELINE config #4
+        gen_model_autocast("tinyM", 2, 32, torch.float16, "f16")     # the MBConv variant under the extraction default (conv_block.py:240-321)
+        gen_model_autocast("tinyM", 2, 32, torch.bfloat16, "bf16")
     if "mbconv" in todo:
         print("G8 MBConv / EfficientNetV2 variant")
         gen_model("tinyM", 2, 32, True)

@@ -191,6 +191,42 @@ def test_mbconv_native_forward_matches_reference_fixture(amd, oracle):
     assert torch.equal(idx_a, idx)
 
 
+@pytest.mark.parametrize("tag", ["f16", "bf16"])
+def test_mbconv_under_autocast_is_no_further_from_exact_than_the_reference(amd, oracle, tag):
+    """The reference's extraction context (`with torch.autocast('cuda')`, extract_embeddings.py:124-125) on the MBConv variant: this
+    package answers with its fp32 MBConv kernels (and a warning) instead of a rounding-faithful 16-bit evaluation.  Against the fixture
+    recorded from the reference under CPU autocast (tests/golden/model_tinyM_<tag>.npz, round 3): the indices equal the reference's
+    fp32 indices bit for bit -- so they agree with its 16-bit indices exactly as often as its own fp32 run does -- and the pre-VQ
+    features are no further from an fp64 evaluation than the reference's 16-bit evaluation is (the criterion of the Fixup path's
+    16-bit tests; here with a wide margin, the arithmetic being fp32)."""
+    from conftest import record_parity
+    from vqae_amd.model import VQAE
+    g = load_golden(f"model_tinyM_{tag}")
+    spec, p = golden_params(oracle, "tinyM", g)
+    x = oracle.make_patches(int(g["batch"]), 32, 0)
+    dt = {"f16": torch.float16, "bf16": torch.bfloat16}[tag]
+    model = VQAE.from_spec(amd.SPECS["tinyM"])
+    model.load_state_dict(p, strict=False)
+    model = model.cuda().eval()
+    with pytest.warns(UserWarning, match="MBConv models run in fp32"):
+        with torch.autocast("cuda", dtype=dt):
+            (q,), (idx,), (loss,) = model.encoder(x.cuda())
+    idx = idx.cpu().numpy().astype(np.int64)
+    assert np.array_equal(idx, g["idx_fp32"].astype(np.int64))
+    agree16 = float((idx == g["idx"].astype(np.int64)).mean())
+    nat = amd.NativeVQAE(amd.SPECS["tinyM"], p)
+    z_hip = nat.encode_features(x.cuda()).permute(0, 3, 1, 2).cpu().double()
+    with torch.autocast("cpu", dtype=dt):
+        z_ref = oracle.encoder_features(x, p, spec).double()
+    p64 = {k: v.double() for k, v in p.items() if torch.is_tensor(v) and v.is_floating_point()}
+    z_ex = oracle.encoder_features(x.double(), p64, spec)
+    eh, er = (z_hip - z_ex).abs(), (z_ref - z_ex).abs()
+    rh, rr = float((eh ** 2).mean().sqrt()), float((er ** 2).mean().sqrt())
+    record_parity("mbconv_autocast_vs_exact_fp64", dtype=tag, idx_agreement_with_ref16=agree16, rms_hip=rh, rms_ref16=rr,
+                  max_hip=float(eh.max()), max_ref16=float(er.max()))
+    assert rh <= 1.25 * rr and float(eh.max()) <= 1.25 * float(er.max()), (rh, rr)
+
+
 def test_mbconv_cfgB_size_matches_reference_fixture(amd, oracle):
     """50 + 50 trunk MBConv blocks at 128 -> 512 channels, 256^2 input (fixture model_BM, batch 2)."""
     g = load_golden("model_BM")

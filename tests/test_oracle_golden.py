@@ -139,6 +139,23 @@ def test_model_BM_matches_reference_fixture(oracle):
     assert np.array_equal(out[:, :, ::16, ::16].numpy(), g["out_sample"])
 
 
+@pytest.mark.parametrize("name,tag,size", [("tiny", "f16", 32), ("tinyP", "bf16", 32), ("tinyM", "f16", 32), ("tinyM", "bf16", 32)])
+def test_small_models_under_cpu_autocast_match_reference_fixture(oracle, name, tag, size):
+    """The oracle under torch.autocast('cpu', dtype) -- the reference's extraction context (extract_embeddings.py:124-125) -- replays the
+    indices, loss and output sample recorded from the reference itself under the same context; round 3 adds the MBConv variant
+    (conv_block.py:240-321, layers/misc.py:23-30: BatchNorm, SiLU and the SE gate under autocast)."""
+    import torch
+    g = load_golden(f"model_{name}_{tag}")
+    spec = oracle.SPECS[name]
+    p = oracle.make_params(spec, 0)
+    p["encoder.vq_layers.0.embed"] = torch.from_numpy(g["embed"])
+    x = oracle.make_patches(int(g["batch"]), size, 0)
+    taps = {}
+    out, losses = oracle.vqae_forward(x, p, spec, taps, dtype={"f16": torch.float16, "bf16": torch.bfloat16}[tag])
+    assert np.array_equal(taps["idx"].numpy().astype(np.int64), g["idx"].astype(np.int64))
+    assert np.array_equal(out.float()[:, :, ::16, ::16].numpy(), g["out_sample"])
+
+
 def test_se_hidden_is_make_divisible(oracle):
     # utils/train_helpers.py:21-24 with divide=True
     assert [oracle.se_hidden(c, 4) for c in (32, 64, 128, 512, 1024, 6)] == [8, 16, 32, 128, 256, 2]

@@ -277,6 +277,9 @@ void wino43_trunk_kernel(const W43K p) {
                 for (int j = 0; j < 4; ++j) {
                     acc[st][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j], bq[s & 1][j], acc[st][0], 0, 0, 0);   // D[channel][tile]
                     acc[st][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[j], bq[s & 1][j], acc[st][1], 0, 0, 0);
+#ifdef W43_ALT
+                    __builtin_amdgcn_sched_barrier(0);                // keep the two accumulators alternating: hipcc otherwise queues 4 dependent MFMAs
+#endif
                 }
                 __builtin_amdgcn_sched_barrier(0);                    // keep the prefetch distances as written
             }

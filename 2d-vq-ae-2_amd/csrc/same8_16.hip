@@ -120,12 +120,19 @@ void same8_16_kernel(const S8K p) {
         }
         lds_barrier();
         // ---- P2: conv2 + conv3 per 32-pixel row segment ------------------------------------------------------------------------------
+        f32x4 res4[4];                                                     // residual rows of the four segments, requested together (L2 hits)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int mt = wave * 4 + i;
+            const int py = mt >> 1, px = (mt & 1) * 32 + li;
+            res4[i] = *reinterpret_cast<const f32x4*>(p.x + (((int64_t)b * p.H + ty0 + py) * p.W + tx0 + px) * 8 + 4 * hh);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int mt = wave * 4 + i;                                   // 16 segments: 8 rows x 2
             const int py = mt >> 1, px = (mt & 1) * 32 + li;
             const int64_t o = (((int64_t)b * p.H + ty0 + py) * p.W + tx0 + px) * 8 + 4 * hh;
-            const f32x4 res = *reinterpret_cast<const f32x4*>(p.x + o);   // residual: consumed after conv3
+            const f32x4 res = res4[i];                                     // residual: consumed after conv3
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -171,6 +178,9 @@ void same8_16_kernel(const S8K p) {
 //   P1  a wave per 32 halo pixels: lane (pixel, hh) loads channels 8 hh .. + 7, pre-activation, one MFMA, lane holds channels
 //       {4 hh .. + 3, 8 + 4 hh .. + 3} -> activation -> t1 (32 B per pixel) in LDS
 //   P2  as the C = 8 form with one tap per k-step (9 steps), two register quads per lane, the lane halves swap one quad each.
+#ifndef SS16_RES_UP
+#define SS16_RES_UP 1
+#endif
 struct S16K {
     const float* __restrict__ x;         // [B][H][W][C] fp32
     float* __restrict__ y;
@@ -264,6 +274,19 @@ void same_small16_kernel(const S16K p) {
         }
         lds_barrier();
         // ---- P2: conv2 + conv3 per 32-pixel row segment ------------------------------------------------------------------------------
+        // the residual rows of all four segments are requested up front (L2 hits: P1 just read them): one latency instead of four
+        constexpr bool RES_UP = SS16_RES_UP;
+        f32x4 res_all[RES_UP ? 4 : 1][NQ];
+        if (RES_UP) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int mt = wave * 4 + i;
+                const int py = mt >> 1, px = (mt & 1) * 32 + li;
+                const int64_t o = (((int64_t)b * p.H + ty0 + py) * p.W + tx0 + px) * C + 4 * hh;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) res_all[i][q] = *reinterpret_cast<const f32x4*>(p.x + o + 8 * q);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int mt = wave * 4 + i;
@@ -271,7 +294,7 @@ void same_small16_kernel(const S16K p) {
             const int64_t o = (((int64_t)b * p.H + ty0 + py) * p.W + tx0 + px) * C + 4 * hh;
             f32x4 res[NQ];
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) res[q] = *reinterpret_cast<const f32x4*>(p.x + o + 8 * q);
+            for (int q = 0; q < NQ; ++q) res[q] = RES_UP ? res_all[i][q] : *reinterpret_cast<const f32x4*>(p.x + o + 8 * q);
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;

@@ -36,13 +36,13 @@ using vqae::lds_barrier;
 
 struct W43K {
     const float* __restrict__ t1;        // [M][C] conv2 input
-    const float* __restrict__ U;         // G g G^T, [36 pos][4 slices][8 k-groups][2 blocks][64 lanes][4]
+    const float* __restrict__ U;         // G g G^T, [36 pos][C / 32 slices][C / 16 k-groups][2 blocks][64 lanes][4]
     const float* __restrict__ w3;        // [C][C], fragment order of conv_wino.hip (k-slice 8)
     const float* __restrict__ w1n;       // same, the next block's conv1 (TAIL == 2)
     float* xio;                          // [M][C] residual stream, updated in place
     float* y2;                           // [M][C] next block's t1 (TAIL == 2)
     int H, M;
-    int stag, first_gen;                 // experiment: delay (x 1024 cycles) of the odd-slot workgroups among the first first_gen
+    int stag, first_gen;                 // developer experiment (VQAE_W43_STAG, default 0 = off): delay (x 1024 cycles) of the odd-slot workgroups among the first first_gen
     float act_a, act_b, t_scale, t_b4, n_b1a, n_b1b, n_b2a, n_b2b;
 };
 

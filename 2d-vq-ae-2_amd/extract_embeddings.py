@@ -551,10 +551,15 @@ def run_eval(model, dataset, batch_size=100, *, autocast_dtype=_REF_AUTOCAST, nu
             if ring is not None:
                 ring.close()
 
+        started = False
         if ring is not None and on_gpu:
             import threading
-            threading.Thread(target=_teardown, name="vqae-loader-teardown").start()
-        else:
+            try:
+                threading.Thread(target=_teardown, name="vqae-loader-teardown").start()
+                started = True
+            except RuntimeError:                                   # interpreter shutting down (a generator finalised late): do it here
+                pass
+        if not started:
             _teardown()
 
 

@@ -327,10 +327,58 @@ def _pool_labels(lab, out_hw):
 _COMPACT = {1: torch.uint8, 2: getattr(torch, "uint16", torch.int16), 4: torch.int32}
 
 
+class _Rechunk:
+    """Re-batches a stream of tile batches for the encoder: tiles go in as the loader delivers them (batches of any size), the
+    encoder is called on exactly `eb` tiles at a time (the last call takes the remainder), code tiles come out in the same order and
+    are handed back in the loader's batch sizes.  Why: the trunk kernels own 128 code-grid pixels = 1/8 of a tile each and a
+    launch fills 512 workgroup slots, so a batch that is not a multiple of 64 tiles leaves the last round of every launch partly
+    empty -- the reference's default of 100 tiles runs the encoder 6.5 % slower than 128.  The encoder is
+    batch-invariant bit for bit (tests/test_configs_gpu.py), so the codes do not depend on where the stream is cut."""
+
+    def __init__(self, enc, eb):
+        self.enc, self.eb = enc, int(eb)
+        self.inq, self.n_in, self.outq, self.n_out = [], 0, [], 0
+
+    @staticmethod
+    def _take(q, n):
+        parts, need = [], n
+        while need > 0:
+            t = q[0]
+            if len(t) <= need:
+                parts.append(q.pop(0))
+                need -= len(t)
+            else:
+                parts.append(t[:need])
+                q[0] = t[need:]
+                need = 0
+        return parts[0] if len(parts) == 1 else torch.cat(parts, 0)
+
+    def _encode(self, n):
+        self.outq.append(self.enc(self._take(self.inq, n)))
+        self.n_in -= n
+        self.n_out += n
+
+    def push(self, x):
+        self.inq.append(x)
+        self.n_in += len(x)
+        while self.n_in >= self.eb:
+            self._encode(self.eb)
+
+    def flush(self):
+        if self.n_in:
+            self._encode(self.n_in)
+
+    def pop(self, n):
+        if self.n_out < n:
+            return None
+        self.n_out -= n
+        return self._take(self.outq, n)
+
+
 @torch.no_grad()
 def run_eval(model, dataset, batch_size=100, *, autocast_dtype=_REF_AUTOCAST, num_workers=6, prefetch_factor=5,
              device=None, shard=True, encode_fn=None, pool_fn=None, loader="auto", timer=None, compact=False,
-             gather_to=None):
+             gather_to=None, encode_batch="auto"):
     """Batched encoder pass: drop-in for run_eval (extract_embeddings.py:92-138).  Yields, per batch, the reference's pair
         ((encoding_indices, names, img_index, patch_index), (labels_pooled, names, img_index, patch_index))
     with tensors on `device`.  Defaults are the reference's: batch 100, 6 loader workers, prefetch 5, page-locked host
@@ -342,6 +390,9 @@ def run_eval(model, dataset, batch_size=100, *, autocast_dtype=_REF_AUTOCAST, nu
     reference builds it; "auto" -- "ring" when it applies.
     compact=True returns the code tiles in the smallest unsigned dtype that holds the codebook (uint8 / uint16; what
     get_encodings stitches and downloads) instead of the reference's int64.
+    encode_batch: tiles per encoder call on one GPU.  "auto" -- the next multiple of 64 when batch_size is not one (the stream of loader
+    batches is re-cut for the encoder and the codes are handed back in the loader's batches, see _Rechunk; the yields are the
+    same, a few batches later), else batch_size; an int forces a size; None keeps one encoder call per loader batch.
 
     Under torch.distributed (one process per GPU) every global batch is sharded contiguously over the ranks: a
     rank's loader reads and its GPU encodes only its share (ShardBatchSampler); the shares are re-assembled with ONE
@@ -448,6 +499,12 @@ def run_eval(model, dataset, batch_size=100, *, autocast_dtype=_REF_AUTOCAST, nu
         return emit(idx, pooled.to(ldt), meta)
 
     pending, grid_hw, copied, encoded, depth = None, None, [], [], 3
+    eb = encode_batch
+    if eb == "auto":
+        # the next multiple of 64 tiles: whole rounds of workgroups, hardly more latency (measured at batch 100, cfg A f16, 100 k tiles:
+        # encoder 6.97 s -> 6.65 s with 128 or 256 per call; end to end 7.91 s -> 7.62 s with 128, 7.95 - 8.04 s with 256: burstier)
+        eb = -(-batch_size // 64) * 64 if (on_gpu and ws == 1 and encode_fn is None and batch_size % 64 != 0 and batch_size < 512) else None
+    rq, waiting = None, []                                         # ws == 1 only: re-cut stream, batches whose codes are still due
     if on_gpu:
         main_stream, copy_stream = torch.cuda.current_stream(device), torch.cuda.Stream(device)
     with _stage(timer, "host", "loader_start"):
@@ -493,9 +550,17 @@ def run_eval(model, dataset, batch_size=100, *, autocast_dtype=_REF_AUTOCAST, nu
                                 copied.pop(0).synchronize()
                 else:
                     x, lab = imgs.to(device), labels.to(device)
-                with _stage(timer, "gpu", "encode"):
-                    idx = enc(x)
-                th, tw = int(idx.shape[-2]), int(idx.shape[-1])
+                if ws == 1 and eb and grid_hw is not None:         # (the first batch is encoded on its own: it tells the grid size)
+                    if rq is None:
+                        rq = _Rechunk(enc, eb)
+                    with _stage(timer, "gpu", "encode"):
+                        rq.push(x)
+                    idx = None
+                    th, tw = grid_hw
+                else:
+                    with _stage(timer, "gpu", "encode"):
+                        idx = enc(x)
+                    th, tw = int(idx.shape[-2]), int(idx.shape[-1])
                 if labels_dtype is None:
                     labels_dtype = labels.dtype
                 with _stage(timer, "gpu", "label_pool"):
@@ -506,9 +571,17 @@ def run_eval(model, dataset, batch_size=100, *, autocast_dtype=_REF_AUTOCAST, nu
                     encoded.append(ev)
                 grid_hw = (th, tw)
             if ws == 1:                                            # the reference's single-GPU loop (:117-138)
-                if compact and idx.dtype == torch.int64:
-                    idx = idx.to(wire_dtype).view(code_dtype)
-                yield emit(idx, pooled.reshape(idx.shape).to(labels_dtype), meta_of(k, n, collated))
+                waiting.append((idx, n, pooled, meta_of(k, n, collated)))
+                while waiting:
+                    idx_w, n_w, pooled_w, meta_w = waiting[0]
+                    if idx_w is None:
+                        idx_w = rq.pop(n_w)
+                        if idx_w is None:
+                            break
+                    waiting.pop(0)
+                    if compact and idx_w.dtype == torch.int64:
+                        idx_w = idx_w.to(wire_dtype).view(code_dtype)
+                    yield emit(idx_w, pooled_w.reshape(idx_w.shape).to(labels_dtype), meta_w)
                 continue
             # ---- sharded: pack my share, launch the gather, and only then hand out the PREVIOUS batch ---------------------
             meta = meta_of(k, n, collated)
@@ -536,6 +609,15 @@ def run_eval(model, dataset, batch_size=100, *, autocast_dtype=_REF_AUTOCAST, nu
             pending = (out, work, n, th, tw, meta, labels_dtype)
         if pending is not None:
             yield finish(pending)
+        if rq is not None:                                         # the tail of the re-cut stream
+            with _stage(timer, "gpu", "encode"):
+                rq.flush()
+            for idx_w, n_w, pooled_w, meta_w in waiting:
+                idx_w = rq.pop(n_w) if idx_w is None else idx_w
+                if compact and idx_w.dtype == torch.int64:
+                    idx_w = idx_w.to(wire_dtype).view(code_dtype)
+                yield emit(idx_w, pooled_w.reshape(idx_w.shape).to(labels_dtype), meta_w)
+            waiting = []
     finally:
         # Joining the worker processes (each unmaps the ring) and un-registering the ring take 0.5 - 1 s together: once the device has
         # drained the copies that read the ring, both run on a helper thread beside whatever the caller does next (the stitch / HDF5

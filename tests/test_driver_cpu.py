@@ -168,6 +168,29 @@ def test_run_eval_get_encodings_single_process(amd, oracle):
     assert sorted(ds.reads) == list(range(42))
 
 
+@pytest.mark.parametrize("eb", [5, 16, 100])
+def test_run_eval_recuts_the_tile_stream_for_the_encoder(amd, oracle, eb):
+    """encode_batch: the encoder sees the stream of tiles in calls of `eb` tiles (the first loader batch on its own, the remainder at
+    the end), the yields keep the loader's batches -- same grids as one encoder call per batch (run_eval's "auto" picks 256 when
+    batch_size is not a multiple of 64: the reference's default of 100 leaves the last round of every trunk launch partly empty)."""
+    from vqae_amd.extract_embeddings import get_encodings
+    g = load_golden("driver")
+    tiles = torch.from_numpy(g["tiles"])
+    ds = _FixtureSlides(g["sizes"])
+    calls = []
+
+    def encode(x):
+        calls.append(int(x.shape[0]))
+        return tiles[x.reshape(-1).long()]
+
+    pool = lambda lab, out: torch.nn.functional.adaptive_max_pool2d(lab.float().reshape(lab.shape[0], 1, *lab.shape[-2:]), out)[:, 0].to(torch.uint8)
+    got = dict(get_encodings(None, ds, batch_size=7, stitch_fn=_cpu_stitch, device="cpu", encode_fn=encode, pool_fn=pool,
+                             num_workers=0, encode_batch=eb))
+    _check_driver(g, ds, got, oracle)
+    rest = 42 - 7
+    assert calls == [7] + [eb] * (rest // eb) + ([rest % eb] if rest % eb else []), calls
+
+
 def test_ring_loader_equals_stock_loader(amd, oracle):
     """loader='ring': worker processes collate straight into the shared ring (PinnedRing; page-locking needs a GPU and is
     skipped here) -- same grids as the stock DataLoader path, with more batches than ring slots so that slots are reused."""

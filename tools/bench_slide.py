@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--loader", default="auto", choices=["auto", "ring", "torch"])
     ap.add_argument("--prefetch", type=int, default=3)
     ap.add_argument("--out", default=None, help="also write the JSON record to this file")
+    ap.add_argument("--encode-batch", default="auto", help="tiles per encoder call: auto (run_eval's default), none, or a number")
     a = ap.parse_args()
     spec = vqae_amd.SPECS["A"]
     torch.manual_seed(0)
@@ -89,7 +90,8 @@ def main():
     torch.cuda.synchronize()
     t0 = time.time()
     save_encodings_hdf5(out, nat, ds, batch_size=a.batch, num_workers=a.workers, prefetch_factor=a.prefetch,
-                        autocast_dtype=adt, loader=a.loader, timer=timer)
+                        autocast_dtype=adt, loader=a.loader, timer=timer,
+                        encode_batch=("auto" if a.encode_batch == "auto" else (None if a.encode_batch == "none" else int(a.encode_batch))))
     torch.cuda.synchronize()
     dt = time.time() - t0
     n = len(ds)
@@ -105,7 +107,7 @@ def main():
         assert np.array_equal(mask[rr * 32:(rr + 1) * 32, cc * 32:(cc + 1) * 32].astype(bool), pooled), (rr, cc)
     rec = {"workload": f"cfg A slide: {a.rows}x{a.cols} tiles of 512x512x3 uint8 -> [{grid.shape[0]},{grid.shape[1]}] "
                        f"{grid.dtype} code grid + {mask.dtype} mask -> HDF5, batch {a.batch}, {a.workers} loader workers "
-                       f"(prefetch {a.prefetch}, loader {a.loader}), {a.dtype}",
+                       f"(prefetch {a.prefetch}, loader {a.loader}, encoder calls {a.encode_batch}), {a.dtype}",
            "patches": n, "seconds": round(dt, 3), "patches_per_s": round(n / dt, 1),
            "encoder_only_patches_per_s": round(enc_rate, 1), "fraction_of_encoder_only": round(n / dt / enc_rate, 3),
            "hdf5_bytes": os.path.getsize(out), "codes_used": int(np.unique(grid).size), "stages": timer.summary(),

@@ -503,8 +503,32 @@ def run_eval(model, dataset, batch_size=100, *, autocast_dtype=_REF_AUTOCAST, nu
     if eb == "auto":
         # the next multiple of 64 tiles: whole rounds of workgroups, hardly more latency (measured at batch 100, cfg A f16, 100 k tiles:
         # encoder 6.97 s -> 6.65 s with 128 or 256 per call; end to end 7.91 s -> 7.62 s with 128, 7.95 - 8.04 s with 256: burstier)
-        eb = -(-batch_size // 64) * 64 if (on_gpu and ws == 1 and encode_fn is None and batch_size % 64 != 0 and batch_size < 512) else None
-    rq, waiting = None, []                                         # ws == 1 only: re-cut stream, batches whose codes are still due
+        per_call = batch_size if ws == 1 else cap                  # tiles this rank encodes per loader batch (cap: its largest share)
+        eb = -(-per_call // 64) * 64 if (on_gpu and encode_fn is None and per_call % 64 != 0 and per_call < 512) else None
+    rq, waiting = None, []                                         # re-cut stream; batches whose codes are still due
+
+    def _launch_share(item):
+        """sharded: my share of one batch (codes + pooled labels, `cap` rows) -> asynchronous all-gather; None while the re-cut
+        encoder stream has not produced the batch's codes yet"""
+        idx_s, n_s, pooled_s, (n_b, meta_b) = item
+        th_, tw_ = grid_hw
+        if idx_s is None:
+            idx_s = rq.pop(n_s)
+            if idx_s is None:
+                return None
+        if idx_s is False:                                         # empty share
+            mine = torch.zeros((cap, th_ * tw_ * (code_bytes + 1)), dtype=torch.uint8, device=device)
+        else:
+            with _stage(timer, "gpu", "pack"):
+                nb = th_ * tw_
+                codes = (idx_s if idx_s.element_size() == code_bytes else idx_s.to(wire_dtype))
+                codes = codes.reshape(idx_s.shape[0], nb).contiguous().view(torch.uint8)
+                mine = torch.zeros((cap, codes.shape[1] + nb), dtype=torch.uint8, device=device)
+                mine[: idx_s.shape[0], : codes.shape[1]] = codes
+                mine[: idx_s.shape[0], codes.shape[1]:] = pooled_s.reshape(idx_s.shape[0], nb).to(torch.uint8)
+        with _stage(timer, "host", "gather_launch"):
+            out, work = vdist.all_gather_shares(mine, async_op=True)
+        return (out, work, n_b, th_, tw_, meta_b, labels_dtype)
     if on_gpu:
         main_stream, copy_stream = torch.cuda.current_stream(device), torch.cuda.Stream(device)
     with _stage(timer, "host", "loader_start"):
@@ -550,7 +574,7 @@ def run_eval(model, dataset, batch_size=100, *, autocast_dtype=_REF_AUTOCAST, nu
                                 copied.pop(0).synchronize()
                 else:
                     x, lab = imgs.to(device), labels.to(device)
-                if ws == 1 and eb and grid_hw is not None:         # (the first batch is encoded on its own: it tells the grid size)
+                if eb and grid_hw is not None:                     # (the first batch is encoded on its own: it tells the grid size)
                     if rq is None:
                         rq = _Rechunk(enc, eb)
                     with _stage(timer, "gpu", "encode"):
@@ -584,32 +608,39 @@ def run_eval(model, dataset, batch_size=100, *, autocast_dtype=_REF_AUTOCAST, nu
                     yield emit(idx_w, pooled_w.reshape(idx_w.shape).to(labels_dtype), meta_w)
                 continue
             # ---- sharded: pack my share, launch the gather, and only then hand out the PREVIOUS batch ---------------------
+            # (with a re-cut encoder stream a batch is launched once its codes exist: every rank launches the gathers in batch
+            # order, one or a few iterations later than it read the batch -- the collectives still pair up by order)
             meta = meta_of(k, n, collated)
-            if imgs is not None:
-                with _stage(timer, "gpu", "pack"):
-                    nb = th * tw
-                    codes = (idx if idx.element_size() == code_bytes else idx.to(wire_dtype))
-                    codes = codes.reshape(idx.shape[0], nb).contiguous().view(torch.uint8)
-                    mine = torch.zeros((cap, codes.shape[1] + nb), dtype=torch.uint8, device=device)
-                    mine[: idx.shape[0], : codes.shape[1]] = codes
-                    mine[: idx.shape[0], codes.shape[1]:] = pooled.reshape(idx.shape[0], nb).to(torch.uint8)
-            else:                                                  # empty share (a last batch shorter than the world size)
+            if imgs is None:                                       # empty share (a last batch shorter than the world size)
                 if grid_hw is None:                                # ... before this rank ever encoded a tile
                     ps = getattr(dataset, "patch_size", None)
                     assert factor is not None and ps is not None, "run_eval: an empty share needs dataset.patch_size and a model factor"
                     grid_hw = (int(ps[0]) // factor, int(ps[1]) // factor)
-                th, tw = grid_hw
-                mine = torch.zeros((cap, th * tw * (code_bytes + 1)), dtype=torch.uint8, device=device)
+                waiting.append((False, 0, None, (n, meta)))
+            else:
+                waiting.append((idx, int(x.shape[0]), pooled, (n, meta)))
             if labels_dtype is None:                               # no tile of mine yet: what every other rank sees in its batches
                 labels_dtype = dataset[0][1].dtype
-            with _stage(timer, "host", "gather_launch"):
-                out, work = vdist.all_gather_shares(mine, async_op=True)
-            if pending is not None:
-                yield finish(pending)
-            pending = (out, work, n, th, tw, meta, labels_dtype)
+            while waiting:
+                launched = _launch_share(waiting[0])
+                if launched is None:
+                    break
+                waiting.pop(0)
+                if pending is not None:
+                    yield finish(pending)
+                pending = launched
+        if ws > 1 and rq is not None:                              # the tail of the re-cut stream, sharded
+            with _stage(timer, "gpu", "encode"):
+                rq.flush()
+            for item in waiting:
+                launched = _launch_share(item)
+                if pending is not None:
+                    yield finish(pending)
+                pending = launched
+            waiting = []
         if pending is not None:
             yield finish(pending)
-        if rq is not None:                                         # the tail of the re-cut stream
+        if ws == 1 and rq is not None:                             # the tail of the re-cut stream
             with _stage(timer, "gpu", "encode"):
                 rq.flush()
             for idx_w, n_w, pooled_w, meta_w in waiting:

@@ -272,6 +272,11 @@ def _sharded_driver_worker(rank, ws, port, q):
         # ... and through the ring loader (one worker process per rank)
         g, ds, got = _run_driver(ws, replicate=True, loader="ring", num_workers=1, prefetch_factor=2)
         _check_driver(g, ds, got, vqae_oracle)
+        # ... and with the encoder stream re-cut (shares of 3 / 4 tiles per batch -> encoder calls of 5: a batch's gather is launched
+        # a few iterations after it was read, at different iterations on the two ranks; the collectives pair up by order)
+        for eb in (5, 2, 64):
+            g, ds, got = _run_driver(ws, replicate=True, encode_batch=eb)
+            _check_driver(g, ds, got, vqae_oracle)
         q.put((rank, True, reads))
     except Exception as e:                                          # surface the failure in the parent
         import traceback

@@ -60,6 +60,24 @@ def test_module_mirror_works_with_driver(amd, oracle):
     assert np.array_equal(grids["images/slide_000"], grids_raw["images/slide_000"])
 
 
+def test_recut_encoder_stream_gives_the_same_grids(amd, oracle):
+    """run_eval calls the encoder on the next multiple of 64 tiles when batch_size is not one (encode_batch="auto"; the stream of
+    loader batches is re-cut, the yields are not): slide grids identical to one encoder call per loader batch, for the default and
+    for forced call sizes that straddle batch and slide boundaries -- the encoder is batch-invariant bit for bit."""
+    from vqae_amd.extract_embeddings import SyntheticSlideDataset, get_encodings
+    g = load_golden("model_tiny")
+    p = oracle.make_params(oracle.SPECS["tiny"], 0)
+    p["encoder.vq_layers.0.embed"] = torch.from_numpy(g["embed"])
+    nat = amd.NativeVQAE(amd.SPECS["tiny"], p)
+    ds = SyntheticSlideDataset([(9, 11), (5, 7), (12, 6)], patch_size=32, raw=True)      # 206 tiles
+    want = dict(get_encodings(nat, ds, batch_size=10, num_workers=2, encode_batch=None))
+    for eb in ("auto", 7, 64, 1000):
+        got = dict(get_encodings(nat, ds, batch_size=10, num_workers=2, encode_batch=eb))
+        assert sorted(got) == sorted(want)
+        for k in want:
+            assert got[k].dtype == want[k].dtype and np.array_equal(got[k], want[k]), (eb, k)
+
+
 def test_save_encodings_hdf5_streams_slide_grids(amd, oracle, tmp_path):
     """BASELINE config 5 shape: slides -> HIP encoder -> stitched grids -> one HDF5 file (groups images/masks,
     keys <stem> / <stem>_mask: convert.py:27-32, camelyon16.py:226-235)."""

@@ -247,33 +247,62 @@ class PinnedRing:
         self.nbytes = self.slot_bytes * self.n_slots
         self._mm = mmap.mmap(-1, self.nbytes)                     # MAP_SHARED | MAP_ANONYMOUS: shared with forked workers
         self._buf = torch.frombuffer(self._mm, dtype=torch.uint8)
-        self.pinned = False
+        self.pinned = False                                        # True once every slot is page-locked
         self._pin_thread = None
+        self._slot_ready = None                                    # one threading.Event per slot while / after pinning
+        self._slots_done = 0
         self._want_pin = bool(pin) and torch.cuda.is_available()
-        self._device = device
+        self._device = None
+        if self._want_pin:                                          # an index for the helper thread (torch.cuda.set_device refuses a bare "cuda")
+            d = torch.device(device) if device is not None else torch.device("cuda")
+            self._device = d.index if d.index is not None else torch.cuda.current_device()
+        self.pin_error = None
 
     def pin_async(self):
-        """Page-lock the mapping on a helper thread (a few GB take 0.3 - 1 s): called AFTER the loader has forked its workers -- a
-        fork while another thread sits inside the driver is best avoided -- so it runs beside the production of the first batches
-        (the workers only write into the mapping).  wait_pinned() before the first DMA from the ring."""
+        """Page-lock the mapping slot by slot on a helper thread (a few GB take 0.4 - 1.2 s in all, ~20 ms per 79 MB slot): called
+        AFTER the loader has forked its workers -- a fork while another thread sits inside the driver is best avoided -- it runs
+        beside the production of the first batches (the workers only write into the mapping), slot 0 first, so that batch k finds
+        slot k registered when it arrives.  wait_pinned(slot) before a DMA from that slot."""
         if not self._want_pin or self._pin_thread is not None or self.pinned:
             return
         import threading
+        self._slot_ready = [threading.Event() for _ in range(self.n_slots)]
 
         def _register():
-            if self._device is not None:
+            try:
                 torch.cuda.set_device(self._device)
-            self.pinned = int(torch.cuda.cudart().cudaHostRegister(self._buf.data_ptr(), self.nbytes, 0)) == 0
+                rt = torch.cuda.cudart()
+                for s_ in range(self.n_slots):
+                    rc = int(rt.cudaHostRegister(self._buf.data_ptr() + s_ * self.slot_bytes, self.slot_bytes, 0))
+                    if rc != 0:
+                        self.pin_error = f"hipHostRegister returned {rc} at slot {s_}"
+                        break
+                    self._slots_done = s_ + 1
+                    self._slot_ready[s_].set()
+                self.pinned = self._slots_done == self.n_slots
+            except Exception as e:                                 # kept for wait_pinned(): a ring that is not page-locked still works, slowly
+                self.pin_error = f"{type(e).__name__}: {e}"
+            finally:
+                for ev in self._slot_ready:                        # never leave a waiter behind
+                    ev.set()
 
         self._pin_thread = threading.Thread(target=_register, name="vqae-ring-pin")
         self._pin_thread.start()
 
-    def wait_pinned(self):
+    def wait_pinned(self, slot=None):
+        """Block until `slot` (default: every slot) is page-locked; warns once if the ring could not be registered."""
         if self._pin_thread is None and not self.pinned:
             self.pin_async()
-        if self._pin_thread is not None:
+        if self._slot_ready is not None and slot is not None and not self.pinned:
+            self._slot_ready[slot].wait()
+            if self.pin_error is None:
+                return True
+        if self._pin_thread is not None and (slot is None or self.pin_error is not None):
             self._pin_thread.join()
             self._pin_thread = None
+            if self._want_pin and not self.pinned:
+                import warnings
+                warnings.warn(f"PinnedRing: the loader ring could not be page-locked ({self.pin_error}); host-to-device copies will be slower")
         return self.pinned
 
     def views(self, slot, n):
@@ -287,8 +316,11 @@ class PinnedRing:
         if self._pin_thread is not None:
             self._pin_thread.join()
             self._pin_thread = None
-        if self.pinned:
-            torch.cuda.cudart().cudaHostUnregister(self._buf.data_ptr())
+        if self._slots_done:
+            rt = torch.cuda.cudart()
+            for s_ in range(self._slots_done):
+                rt.cudaHostUnregister(self._buf.data_ptr() + s_ * self.slot_bytes)
+            self._slots_done = 0
             self.pinned = False
         self._buf = None
         try:
@@ -530,7 +562,9 @@ def run_eval(model, dataset, batch_size=100, *, autocast_dtype=_REF_AUTOCAST, nu
             out, work = vdist.all_gather_shares(mine, async_op=True)
         return (out, work, n_b, th_, tw_, meta_b, labels_dtype)
     if on_gpu:
-        main_stream, copy_stream = torch.cuda.current_stream(device), torch.cuda.Stream(device)
+        # the copy stream gets a high-priority hardware queue of its own: an ordinary stream may land on the queue the encoder's
+        # launches sit in (HIP deals its few hardware queues round-robin) and every copy then waits behind up to `depth` batches of kernels
+        main_stream, copy_stream = torch.cuda.current_stream(device), torch.cuda.Stream(device, priority=-1)
     with _stage(timer, "host", "loader_start"):
         it = iter(dl)
     if ring is not None:
@@ -555,9 +589,9 @@ def run_eval(model, dataset, batch_size=100, *, autocast_dtype=_REF_AUTOCAST, nu
                     if len(encoded) >= depth:
                         with _stage(timer, "host", "encoder_backpressure"):
                             encoded.pop(0).synchronize()
-                    if use_ring and k == 0:
+                    if use_ring and k < ring.n_slots:              # the slots are page-locked in order, beside the first batches
                         with _stage(timer, "host", "ring_pin_wait"):
-                            ring.wait_pinned()
+                            ring.wait_pinned(k % ring.n_slots)
                     with torch.cuda.stream(copy_stream):
                         with _stage(timer, "gpu", "h2d"):
                             x = imgs.to(device, non_blocking=True)

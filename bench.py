@@ -340,6 +340,7 @@ def main():
     ap.add_argument("--prof-class", type=int, default=1, help="kernel class timed for `roofline` (1 = trunk 3x3 conv)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short legs of the other BASELINE configs that the default N = 1 line carries")
+    ap.add_argument("--no-slide-leg", action="store_true", help="skip the whole-slide extraction leg of other_configs")
     ap.add_argument("--other-steps", type=int, default=5)
     args = ap.parse_args()
 
@@ -377,7 +378,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_other_configs and \
             (args.config, args.dtype, args.batch, args.mode, args.prof_class) == ("B", "f32", 256, "full", 1):
         other = {}
-        for key, cfgname, dt, mode, pclass in OTHER_LEGS:
+        for key, cfgname, dt, mode, pclass in ([] if os.environ.get("VQAE_BENCH_ONLY_SLIDE") else OTHER_LEGS):
             leg = argparse.Namespace(**vars(args))
             leg.config, leg.dtype, leg.mode, leg.prof_class = cfgname, dt, mode, pclass
             leg.steps, leg.warmup, leg.no_cpu_baseline = args.other_steps, 2, True
@@ -388,6 +389,32 @@ def main():
                                                 "roofline", "value_with_h2d") if k in r}
             except Exception as e:          # a failed leg must not take the headline line with it
                 other[key] = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.empty_cache()
+        # BASELINE configs[4] on this one GPU, end to end: 20 000 uint8 512 x 512 tiles of one synthetic slide -> ring loader (8 worker
+        # processes, CPU only) -> cfg A encoder + VQ under f16 autocast -> device-side stitching -> HDF5 (tools/bench_slide.py; the
+        # 100 000-tile record is profiles/r03_slide.json: at 20 000 tiles the fixed start-up weighs 5x more)
+        if not args.no_slide_leg:
+            free_b, total_b = torch.cuda.mem_get_info()
+            log(f"other_configs leg configs[4]_slide_pipeline_1gpu (device memory free {free_b / 2**30:.1f} of {total_b / 2**30:.1f} GiB, "
+                f"torch reserved {torch.cuda.memory_reserved() / 2**30:.1f} GiB)")
+            try:
+                # a child process (this one stays alive and idle): inside this process the ring loader's host-to-device copies complete
+                # 10-40x later than in a fresh one (16 - 75 ms per 79 MB batch instead of 2; measured, cause not found), which would
+                # make the leg a measurement of that, not of the pipeline
+                import subprocess
+                cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_slide.py"), "--rows", "100", "--cols", "200", "--batch", "100",
+                       "--workers", "8", "--prefetch", "2", "--dtype", "f16", "--loader", "ring"]
+                cp = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+                lines = [l for l in cp.stdout.splitlines() if l.startswith("{")]
+                if cp.returncode != 0 or not lines:
+                    raise RuntimeError(f"bench_slide.py exited {cp.returncode}: {cp.stderr[-300:]}")
+                rec = json.loads(lines[-1])
+                other["configs[4]_slide_pipeline_1gpu"] = {"value": rec["patches_per_s"], "unit": "patches/s", "seconds": rec["seconds"],
+                                                           "patches": rec["patches"], "dtype": "f16",
+                                                           "encoder_only_patches_per_s": rec["encoder_only_patches_per_s"],
+                                                           "config": {"workload": rec["workload"]}, "stages": rec["stages"]}
+            except Exception as e:
+                other["configs[4]_slide_pipeline_1gpu"] = {"error": f"{type(e).__name__}: {e}"}
             torch.cuda.empty_cache()
         res["other_configs"] = other
     if rank == 0:

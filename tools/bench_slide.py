@@ -54,6 +54,17 @@ def main():
     ap.add_argument("--out", default=None, help="also write the JSON record to this file")
     ap.add_argument("--encode-batch", default="auto", help="tiles per encoder call: auto (run_eval's default), none, or a number")
     a = ap.parse_args()
+    rec = run_slide(a)
+    print(json.dumps(rec))
+    if a.out:
+        os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+        with open(a.out, "w") as f:
+            json.dump(rec, f, indent=1)
+
+
+def run_slide(a):
+    """One whole-slide extraction (a: namespace with rows, cols, batch, workers, dtype, loader, prefetch, encode_batch); returns the record.
+    bench.py calls it for its `other_configs` leg of BASELINE configs[4] on one GPU."""
     spec = vqae_amd.SPECS["A"]
     torch.manual_seed(0)
     model = VQAE.from_spec(spec).eval()
@@ -112,12 +123,8 @@ def main():
            "encoder_only_patches_per_s": round(enc_rate, 1), "fraction_of_encoder_only": round(n / dt / enc_rate, 3),
            "hdf5_bytes": os.path.getsize(out), "codes_used": int(np.unique(grid).size), "stages": timer.summary(),
            "host_cores": len(os.sched_getaffinity(0))}
-    print(json.dumps(rec))
-    if a.out:
-        os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
-        with open(a.out, "w") as f:
-            json.dump(rec, f, indent=1)
     os.remove(out)
+    return rec
 
 
 if __name__ == "__main__":

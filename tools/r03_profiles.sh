@@ -39,7 +39,7 @@ tail -1 gpurun_out/r03/vq_proj_bench.log
 bash tools/pmc_run.sh r03_vq16_a vq_proj16 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_WAIT_INST_LDS -- tools/vq_proj_bench.py --reps 3 > gpurun_out/r03/pmc_vq16_a.json || exit 1
 bash tools/pmc_run.sh r03_vq16_b vq_proj16 SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES -- tools/vq_proj_bench.py --reps 3 > gpurun_out/r03/pmc_vq16_b.json || exit 1
 bash tools/pmc_run.sh r03_vq16_c vq_proj16 GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum TCP_PENDING_STALL_CYCLES_sum -- tools/vq_proj_bench.py --reps 3 > gpurun_out/r03/pmc_vq16_c.json || echo "(TCC/TCP pass not available)"
-timeout -k 10 400 python tools/bench_slide.py --rows 250 --cols 400 --batch 100 --workers 10 --prefetch 2 --dtype f16 --loader ring --out gpurun_out/r03/slide_100k.json > gpurun_out/r03/slide_100k.log 2>&1 || { echo "slide failed"; exit 1; }
+timeout -k 10 400 python tools/bench_slide.py --rows 250 --cols 400 --batch 100 --workers 8 --prefetch 2 --dtype f16 --loader ring --out gpurun_out/r03/slide_100k.json > gpurun_out/r03/slide_100k.log 2>&1 || { echo "slide failed"; exit 1; }
 tail -1 gpurun_out/r03/slide_100k.log | cut -c1-400
 # the default line (what the driver runs), last: with the traffic figures in place
 timeout -k 10 400 python bench.py > gpurun_out/r03/bench_default.log 2>&1; tail -1 gpurun_out/r03/bench_default.log | cut -c1-600

@@ -60,6 +60,28 @@ def test_module_mirror_works_with_driver(amd, oracle):
     assert np.array_equal(grids["images/slide_000"], grids_raw["images/slide_000"])
 
 
+def test_pinned_ring_is_really_page_locked(amd):
+    """PinnedRing.pin_async registers the shared mapping slot by slot on a helper thread (round 3: an earlier form handed
+    torch.cuda.set_device a bare 'cuda' device there, the thread died, and the ring silently stayed pageable): every slot ends up
+    page-locked as torch sees it, for a device given with and without an index, and close() releases it."""
+    import warnings
+    from vqae_amd.extract_embeddings import PinnedRing
+    for dev in (torch.device("cuda"), torch.device("cuda", 0), None):
+        ring = PinnedRing(5, 3, (16, 16, 3), torch.uint8, (1, 16, 16), torch.uint8, pin=True, device=dev)
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                            # a failed registration warns: make that a failure here
+            ring.pin_async()
+            assert ring.wait_pinned(0) and ring.wait_pinned(4)
+            assert ring.wait_pinned() is True and ring.pin_error is None
+        for slot in range(5):
+            imgs, labs = ring.views(slot, 3)
+            assert imgs.is_pinned() and labs.is_pinned()
+            imgs.fill_(slot)
+            assert int(imgs.to("cuda", non_blocking=True).sum().item()) == slot * imgs.numel()
+        ring.close()
+        assert not ring.pinned
+
+
 def test_recut_encoder_stream_gives_the_same_grids(amd, oracle):
     """run_eval calls the encoder on the next multiple of 64 tiles when batch_size is not one (encode_batch="auto"; the stream of
     loader batches is re-cut, the yields are not): slide grids identical to one encoder call per loader batch, for the default and

@@ -20,6 +20,28 @@ if "pinhost" in what:
         xd.copy_(host, non_blocking=True)
     torch.cuda.synchronize()
     del x, host, xd
+if "pinalloc" in what:                      # allocation only, kept alive
+    keep = torch.empty(256, 3, 512, 512).pin_memory()
+if "pincopy_keep" in what:                  # allocation + copies, kept alive
+    keep = torch.empty(256, 3, 512, 512).pin_memory()
+    xd = torch.empty(256, 3, 512, 512, device="cuda")
+    for _ in range(3):
+        xd.copy_(keep, non_blocking=True)
+    torch.cuda.synchronize()
+if "pincopy_small" in what:                 # a small pinned copy only
+    keep = torch.empty(1024).pin_memory()
+    xd = torch.empty(1024, device="cuda")
+    xd.copy_(keep, non_blocking=True)
+    torch.cuda.synchronize()
+if "d2h" in what:                           # a big device-to-host copy into pageable memory
+    x = torch.empty(256, 3, 512, 512, device="cuda")
+    h = x.cpu()
+    del x, h
+if "hostcache" in what:
+    try:
+        torch._C._host_emptyCache()
+    except Exception as e:
+        print("no _host_emptyCache:", e)
 if "events" in what:
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(6000)]
     for e in evs: e.record()

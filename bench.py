@@ -378,7 +378,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_other_configs and \
             (args.config, args.dtype, args.batch, args.mode, args.prof_class) == ("B", "f32", 256, "full", 1):
         other = {}
-        for key, cfgname, dt, mode, pclass in ([] if os.environ.get("VQAE_BENCH_ONLY_SLIDE") else OTHER_LEGS):
+        for key, cfgname, dt, mode, pclass in OTHER_LEGS:
             leg = argparse.Namespace(**vars(args))
             leg.config, leg.dtype, leg.mode, leg.prof_class = cfgname, dt, mode, pclass
             leg.steps, leg.warmup, leg.no_cpu_baseline = args.other_steps, 2, True
